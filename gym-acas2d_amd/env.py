@@ -1,0 +1,151 @@
+"""ACAS2DEnv -- single-env adapter with the reference's exact gym surface
+(gym_ACAS2D/envs/environment.py:8-54): old-API ``reset() -> obs`` and
+``step(action) -> (obs, reward, done, info)``, numpy float64 in and out, so that the
+reference's ``*_main.py`` loops (``baseline_main.py:32-61``, ``testing_main.py:62-105``) run
+unchanged.  Arithmetic runs in the same HIP kernel as the batched path (E = 1, float64).
+
+``reset()`` draws the episode from Python's global ``random`` in the reference's draw order
+(reset_parity.py), so ``random.seed(13)`` reproduces the reference's episodes.
+"""
+import random
+
+import numpy as np
+import torch
+
+from .config import ACAS2DConfig
+from .reset_parity import draw_episode
+from .spaces import Box
+from .vec_env import ACAS2DVecEnv
+
+
+class _AircraftView:
+    def __init__(self, x, y, psi, v_air):
+        self.x, self.y, self.psi, self.v_air = x, y, psi, v_air
+
+
+class GameView:
+    """The attributes of ACAS2DGame that the reference's scripts read after/during an episode
+    (testing_main.py:66-105, baseline_main.py:36-58): outcome, steps, total_reward, quit,
+    episode, player, traffic, goal_x/goal_y, path, traffic_paths."""
+
+    def __init__(self, env):
+        self._env = env
+        self.episode = None
+        self.quit = False            # window-close flag of the pygame view (game.py:37,318-321)
+        self.manual = False
+        self.path = []               # game.py:47,132,231
+        self.traffic_paths = []      # game.py:49-50,134-135,232-233 (logged BEFORE traffic moves)
+
+    def _scalar(self, t):
+        return t[0].item()
+
+    @property
+    def steps(self):
+        return int(self._scalar(self._env._vec.steps))
+
+    @property
+    def total_reward(self):
+        return float(self._scalar(self._env._vec.total_reward))
+
+    @property
+    def outcome(self):
+        s = int(self._scalar(self._env._vec.status))
+        return None if s == 0 else s
+
+    @property
+    def running(self):
+        return self.outcome is None
+
+    @property
+    def num_traffic(self):
+        return self._env.config.n_traffic
+
+    @property
+    def goal_x(self):
+        return float(self._scalar(self._env._vec.goal_x))
+
+    @property
+    def goal_y(self):
+        return float(self._scalar(self._env._vec.goal_y))
+
+    @property
+    def player(self):
+        v = self._env._vec
+        return _AircraftView(*(float(self._scalar(t)) for t in (v.own_x, v.own_y, v.own_psi, v.own_v)))
+
+    @property
+    def traffic(self):
+        v = self._env._vec
+        cols = [t[0].cpu().numpy() for t in (v.trf_x, v.trf_y, v.trf_psi, v.trf_v)]
+        return [_AircraftView(*(float(c[n]) for c in cols)) for n in range(self.num_traffic)]
+
+
+class ACAS2DEnv:
+    metadata = {"render.modes": ["human"]}
+
+    def __init__(self, n_traffic=1, device="cuda", config=None, record_paths=True):
+        self.config = config if config is not None else ACAS2DConfig(n_traffic=n_traffic)
+        self._vec = ACAS2DVecEnv(1, device=device, dtype=torch.float64, auto_reset=False,
+                                 config=self.config)
+        self.record_paths = record_paths
+        lo, hi = self.config.obs_low_high()
+        self.observation_space = Box(low=np.array(lo, np.float64), high=np.array(hi, np.float64),
+                                     dtype=np.float64)                       # environment.py:18-21
+        self.action_space = Box(low=-1, high=1, shape=(1,), dtype=np.float64)   # environment.py:27
+        self.game = GameView(self)
+        self._new_game()             # the reference constructs a game in __init__ (environment.py:12)
+
+    def _new_game(self):
+        own, trf, goal = draw_episode(self.config, random)
+        obs = self._vec.set_state(own[None], trf[None], goal[None], steps=np.zeros(1, np.int32))
+        episode = self.game.episode
+        self.game = GameView(self)
+        self.game.episode = episode
+        if self.record_paths:
+            self.game.path.append((own[0], own[1]))
+            self.game.traffic_paths = [[(t[0], t[1])] for t in trf]
+        self._last_trf = trf[:, :2].copy()
+        return obs
+
+    def reset(self):
+        """environment.py:44-48.  NB the reference's observe() in reset() leaves steps == 1."""
+        # _new_game() ran observe() through set_state(); undo nothing: steps is now 1 as in the reference
+        obs = self._new_game()
+        return obs[0].cpu().numpy().astype(np.float64)
+
+    def step(self, action):
+        """environment.py:29-42 (without the pygame clock throttle of :31)."""
+        a = np.asarray(action, dtype=np.float64).reshape(-1)[:1]
+        obs, reward, done, _ = self._vec.step(a)
+        if self.record_paths:
+            v = self._vec
+            self.game.path.append((v.own_x[0].item(), v.own_y[0].item()))
+            for n, lst in enumerate(self.game.traffic_paths):
+                lst.append((float(self._last_trf[n, 0]), float(self._last_trf[n, 1])))
+            self._last_trf = np.stack([v.trf_x[0].cpu().numpy(), v.trf_y[0].cpu().numpy()], axis=1)
+        return (obs[0].cpu().numpy().astype(np.float64), float(reward[0].item()),
+                bool(done[0].item()), {})
+
+    def render(self, mode="human"):
+        """The pygame HUD (game.py:316-431) is split out of the GPU path; no-op here."""
+        return None
+
+    def close(self):
+        self._vec.close()
+
+    def seed(self, seed=None):
+        random.seed(seed)
+        return [seed]
+
+
+def register_with_gym():
+    """gym.make("ACAS2D-v0") (gym_ACAS2D/__init__.py:3-6) if gym happens to be installed."""
+    try:
+        from gym.envs.registration import register   # type: ignore
+    except Exception:  # noqa: BLE001
+        return False
+    try:
+        register(id="ACAS2D-v0", entry_point="gym_acas2d_amd:ACAS2DEnv")
+    except Exception:  # noqa: BLE001  (already registered)
+        pass
+    return True

@@ -1,0 +1,291 @@
+"""ACAS2DVecEnv -- E independent ACAS2D episodes resident in HBM, advanced by one HIP kernel
+launch per ``step()``.
+
+Boundary: the reference's ``ACAS2DEnv.reset()/step()`` surface
+(gym_ACAS2D/envs/environment.py:29-48) widened to a batch with Stable-Baselines3 ``VecEnv``
+semantics, because that is what ``training_main.py:44-52`` wraps the env in
+(``Monitor`` + ``DummyVecEnv``): auto-reset on done, the returned observation is the new
+episode's first observation, the finished episode's last observation and its return / length
+are reported through ``infos[i]["terminal_observation"]`` / ``infos[i]["episode"]``.
+(SB3 1.1.0 is not vendored in the reference: these semantics are *parity unpinned* by any
+reference test and follow SB3's documented behaviour.)
+
+All tensors live on the GPU; nothing here computes step arithmetic on the host.
+"""
+import ctypes as C
+from collections.abc import Sequence
+
+import numpy as np
+import torch
+
+from . import native
+from .config import ACAS2DConfig
+from .spaces import Box
+
+_STATE_FIELDS = ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y",
+                 "trf_x", "trf_y", "trf_psi", "trf_v")
+
+
+class LazyInfos(Sequence):
+    """``infos`` of one step as a sequence of dicts built on demand (a Python list of 65 536
+    dicts per step would dominate the step time).  Tensor views of the same data:
+    ``done``, ``outcome``, ``terminal_observation``, ``episode_return``, ``episode_steps``."""
+
+    def __init__(self, env):
+        self._env = env
+        self.done = env._done.view(torch.bool)
+        self.outcome = env._outcome
+        self.terminal_observation = env._term_obs
+        self.episode_return = env._ep_return
+        self.episode_steps = env._ep_steps
+        self._host = None
+
+    def __len__(self):
+        return self._env.num_envs
+
+    def _fetch(self):
+        if self._host is None:
+            done = self.done.cpu().numpy()
+            idx = np.nonzero(done)[0]
+            h = {"done": done, "idx": idx}
+            if len(idx) and self._env.auto_reset:
+                sel = torch.as_tensor(idx, device=self.done.device)
+                h["outcome"] = self.outcome[sel].cpu().numpy()
+                h["r"] = self.episode_return[sel].cpu().numpy()
+                h["steps"] = self.episode_steps[sel].cpu().numpy()
+                h["tobs"] = (self.terminal_observation[sel].cpu().numpy()
+                             if self.terminal_observation is not None else None)
+                h["pos"] = {int(e): k for k, e in enumerate(idx)}
+            self._host = h
+        return self._host
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        h = self._fetch()
+        i = int(i) % len(self)
+        if not h["done"][i] or not self._env.auto_reset:
+            return {}
+        k = h["pos"][i]
+        info = {"outcome": int(h["outcome"][k]),
+                # Monitor semantics: l = number of step() calls = game.steps - 1 (game.py:197)
+                "episode": {"r": float(h["r"][k]), "l": int(h["steps"][k]) - 1,
+                            "steps": int(h["steps"][k])}}
+        if h["tobs"] is not None:
+            info["terminal_observation"] = h["tobs"][k]
+        return info
+
+
+class ACAS2DVecEnv:
+    """Batched ACAS2D on one GPU.
+
+    num_envs       envs of THIS shard (one process per GPU; see sharding.shard_range)
+    n_traffic      traffic aircraft per env (reference default 1, settings.py:31-32)
+    dtype          torch.float32 (throughput) or torch.float64 (parity with the float64 reference)
+    seed           key of the counter-based reset RNG (reference RANDOM_SEED = 13, settings.py:28)
+    env_offset     global index of this shard's env 0: episodes depend on (seed, global index,
+                   episode counter) only, never on how the envs are sharded
+    auto_reset     VecEnv semantics (True) or the single-env "latch the outcome, freeze the
+                   traffic" semantics of the reference (False; game.py:243-245)
+    """
+
+    metadata = {"render.modes": []}
+
+    def __init__(self, num_envs, n_traffic=1, device="cuda", dtype=torch.float32, seed=13,
+                 env_offset=0, auto_reset=True, keep_terminal_obs=True, config=None):
+        if config is None:
+            config = ACAS2DConfig(n_traffic=n_traffic)
+        self.config = config
+        self.num_envs = int(num_envs)
+        self.n_traffic = int(config.n_traffic)
+        self.obs_dim = config.obs_dim
+        self.dtype = dtype
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError("dtype must be torch.float32 or torch.float64")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ACAS2DVecEnv runs on an AMD GPU (device='cuda'); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible to torch -- the ACAS2D engine has no CPU fallback")
+        self._lib = native.lib()          # raises if the HIP extension is missing
+        self._step_fn = self._lib.acas2d_step_f32 if dtype == torch.float32 else self._lib.acas2d_step_f64
+        self._reset_fn = self._lib.acas2d_reset_f32 if dtype == torch.float32 else self._lib.acas2d_reset_f64
+        self.seed_value = int(seed)
+        self.env_offset = int(env_offset)
+        self.auto_reset = bool(auto_reset)
+        self._ccfg = config.to_c()
+
+        E, N, D, dev = self.num_envs, self.n_traffic, self.obs_dim, self.device
+        z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=dev)  # noqa: E731
+        self.own_x, self.own_y, self.own_psi, self.own_v = z(E), z(E), z(E), z(E)
+        self.goal_x, self.goal_y = z(E), z(E)
+        self.trf_x, self.trf_y, self.trf_psi, self.trf_v = z(E, N), z(E, N), z(E, N), z(E, N)
+        self.steps = z(E, dt=torch.int32)
+        self.total_reward = z(E)
+        self.status = z(E, dt=torch.uint8)
+        self.episode = z(E, dt=torch.int32)            # bit pattern of the u32 counter
+        self._actions = z(E)
+        self._obs = z(E, D)
+        self._reward = z(E)
+        self._done = z(E, dt=torch.uint8)
+        self._outcome = z(E, dt=torch.uint8)
+        self._term_obs = z(E, D) if (keep_terminal_obs and auto_reset) else None
+        self._ep_return = z(E)
+        self._ep_steps = z(E, dt=torch.int32)
+
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        self._cstate = native.CState(*[ptr(getattr(self, n)) for n, _ in native.CState._fields_])
+        self._cio = native.CStepIO(ptr(self._actions), ptr(self._obs), ptr(self._reward), ptr(self._done),
+                                   ptr(self._outcome), ptr(self._term_obs), ptr(self._ep_return),
+                                   ptr(self._ep_steps))
+        self._flags = native.AUTO_RESET if self.auto_reset else 0
+
+        lo, hi = config.obs_low_high()
+        np_dt = np.float32 if dtype == torch.float32 else np.float64
+        self.observation_space = Box(low=np.array(lo, np_dt), high=np.array(hi, np_dt), dtype=np_dt)
+        self.action_space = Box(low=-1, high=1, shape=(1,), dtype=np_dt)   # environment.py:27
+        self._pending = None
+        self._closed = False
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _launch_reset(self, mask, do_init, with_obs=True):
+        native.check(self._reset_fn(
+            C.byref(self._ccfg), C.byref(self._cstate), None if mask is None else mask.data_ptr(),
+            self._obs.data_ptr() if with_obs else None, int(do_init), self.seed_value,
+            self.env_offset, self.num_envs, self.n_traffic, self._stream()))
+
+    # ---- gym / VecEnv surface -------------------------------------------------------------------
+    def seed(self, seed=None):
+        if seed is not None:
+            self.seed_value = int(seed)
+        return [self.seed_value + i for i in range(min(self.num_envs, 16))]
+
+    def reset(self):
+        """environment.py:44-48 for every env: fresh episodes from the counter-based RNG
+        (episode counters restart at 0), first observation returned ([E, 5+3N], device tensor)."""
+        with torch.cuda.device(self.device):
+            self.episode.zero_()
+            self._launch_reset(None, do_init=1)
+        return self._obs
+
+    def reset_masked(self, mask):
+        """Re-initialise the envs with mask != 0 (uint8/bool tensor [E]); their episode counter
+        is advanced first so that they get a new episode."""
+        m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            self.episode.add_(m.to(torch.int32))
+            self._launch_reset(m, do_init=1)
+        return self._obs
+
+    def set_state(self, own, traffic, goal=None, steps=None):
+        """Inject state (oracle vectors / host parity reset): own [E,4] = (x, y, psi, v),
+        traffic [E,N,4], goal [E,2] or [2] (default: the config's goal), steps [E] = game.steps
+        BEFORE the next observe().  Returns the observation observe() yields on that state
+        (which increments steps, game.py:197)."""
+        E, N = self.num_envs, self.n_traffic
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=self.dtype).to(self.device)  # noqa: E731
+        own, traffic = t(own).reshape(E, 4), t(traffic).reshape(E, N, 4)
+        goal = t(self.config.goal if goal is None else goal)
+        goal = goal.expand(E, 2) if goal.dim() == 1 else goal.reshape(E, 2)
+        with torch.cuda.device(self.device):
+            for k, name in enumerate(("own_x", "own_y", "own_psi", "own_v")):
+                getattr(self, name).copy_(own[:, k])
+            for k, name in enumerate(("trf_x", "trf_y", "trf_psi", "trf_v")):
+                getattr(self, name).copy_(traffic[:, :, k])
+            self.goal_x.copy_(goal[:, 0])
+            self.goal_y.copy_(goal[:, 1])
+            if steps is None:
+                self.steps.zero_()
+            else:
+                self.steps.copy_(torch.as_tensor(np.asarray(steps), dtype=torch.int32).to(self.device).reshape(E))
+            self._launch_reset(None, do_init=0)
+        return self._obs
+
+    def step_async(self, actions):
+        """game.py:225 takes action[0] in [-1, 1]; accepts [E], [E,1], numpy or tensor."""
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions, dtype=np.float64))
+        a = actions.reshape(-1)
+        if a.numel() != self.num_envs:
+            raise ValueError("expected %d actions, got %d" % (self.num_envs, a.numel()))
+        with torch.cuda.device(self.device):
+            self._actions.copy_(a, non_blocking=True)
+            native.check(self._step_fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(self._cio),
+                                       self._flags, self.seed_value, self.env_offset, self.num_envs,
+                                       self.n_traffic, self._stream()))
+        self._pending = True
+
+    def step_wait(self):
+        self._pending = None
+        return self._obs, self._reward, self._done.view(torch.bool), LazyInfos(self)
+
+    def step(self, actions):
+        """environment.py:29-42 for every env.  Returns (obs [E,D], reward [E], done [E] bool,
+        infos) as device tensors that are overwritten by the next step()."""
+        self.step_async(actions)
+        return self.step_wait()
+
+    def step_inplace(self):
+        """Launch one step reading the actions already stored in ``self.actions_buffer`` --
+        the zero-copy path for on-device policies and the benchmark (graph-capturable)."""
+        native.check(self._step_fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(self._cio),
+                                   self._flags, self.seed_value, self.env_offset, self.num_envs,
+                                   self.n_traffic, self._stream()))
+
+    def step_from(self, actions_ptr_tensor):
+        """Launch one step reading actions from another resident tensor ([E], same dtype) without
+        copying them (e.g. row t of a pre-generated [T, E] action buffer)."""
+        a = actions_ptr_tensor
+        assert a.dtype == self.dtype and a.numel() == self.num_envs and a.is_contiguous() and a.device == self.device
+        io = native.CStepIO.from_buffer_copy(self._cio)
+        io.actions = a.data_ptr()
+        native.check(self._step_fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io),
+                                   self._flags, self.seed_value, self.env_offset, self.num_envs,
+                                   self.n_traffic, self._stream()))
+
+    @property
+    def actions_buffer(self):
+        return self._actions
+
+    @property
+    def outputs(self):
+        return {"obs": self._obs, "reward": self._reward, "done": self._done.view(torch.bool),
+                "outcome": self._outcome, "terminal_observation": self._term_obs,
+                "episode_return": self._ep_return, "episode_steps": self._ep_steps}
+
+    def close(self):
+        self._closed = True
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is split out of the GPU path (reference game.py:316-431)")
+
+    # ---- SB3 VecEnv shims (training_main.py hands the env to SB3) -------------------------------
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(list(indices))
+        return [getattr(self, attr_name)] * n
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        return [getattr(self, method_name)(*args, **kwargs)]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        n = self.num_envs if indices is None else len(list(indices))
+        return [False] * n
+
+    # ---- checkpoint: the env state IS the SoA tensors ---------------------------
+    def state_dict(self):
+        names = _STATE_FIELDS + ("steps", "total_reward", "status", "episode")
+        return {n: getattr(self, n).clone() for n in names}
+
+    def load_state_dict(self, sd):
+        for n, v in sd.items():
+            getattr(self, n).copy_(v)
+
+    def algorithmic_bytes_per_step(self):
+        s = 4 if self.dtype == torch.float32 else 8
+        return self.num_envs * ACAS2DConfig.algorithmic_bytes_per_env_step(self.n_traffic, s)

@@ -1,0 +1,162 @@
+/*
+ * acas2d.h -- C ABI of the MI355X-native batched ACAS2D step engine (libacas2d_hip.so).
+ *
+ * The reference (Christos-14/gym-ACAS2D) is pure Python and has no FFI; the boundary it exposes
+ * for this path is the gym.Env surface  ACAS2DEnv.reset() / ACAS2DEnv.step(action)
+ * (gym_ACAS2D/envs/environment.py:29-48).  Each entry point below names the reference interface
+ * it replaces.  The Python host (gym-acas2d_amd/) binds these with ctypes; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary;
+ *   - every pointer in Acas2dState / Acas2dStepIO is a DEVICE pointer owned by the caller; the
+ *     library allocates nothing, keeps no global state besides a thread-local error string;
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream) and are safe to capture into a hipGraph;
+ *   - return value: 0 on success, negative ACAS2D_E* on failure, text via acas2d_last_error();
+ *     no exceptions cross the ABI.  Where the reference raises ValueError for NaN headings
+ *     (rewards.py:6-9) the engine propagates NaN instead;
+ *   - `_f32` / `_f64` give the element type of every floating-point buffer (`void*` fields).
+ *
+ * Data layout in HBM (struct of arrays; E = n_envs, N = n_traffic, D = 5 + 3N):
+ *   own_x, own_y, own_psi, own_v           T[E]      player aircraft      (aircraft.py:8-14)
+ *   goal_x, goal_y                         T[E]      goal position        (game.py:80-81)
+ *   trf_x, trf_y, trf_psi, trf_v           T[E][N]   traffic block, env-major so that one env's
+ *                                                    block is contiguous  (game.py:96-116)
+ *   steps                                  i32[E]    game.steps           (game.py:30,197)
+ *   total_reward                           T[E]      game.total_reward    (game.py:32,287)
+ *   status                                 u8[E]     0 = running, else latched outcome
+ *                                                    (game.running/outcome, game.py:36,39)
+ *   episode                                u32[E]    reset counter (input of the reset RNG)
+ *   actions T[E]; obs T[E][D] row-major; reward T[E]; done u8[E]; outcome u8[E]
+ */
+#ifndef ACAS2D_H
+#define ACAS2D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACAS2D_ABI_VERSION 1
+
+/* error codes */
+#define ACAS2D_OK 0
+#define ACAS2D_EINVAL (-22)  /* bad argument (NULL pointer, n_traffic < 1, ...) */
+#define ACAS2D_EHIP (-5)     /* HIP runtime error at launch */
+
+/* step flags */
+#define ACAS2D_AUTO_RESET 1u /* SB3 VecEnv semantics: reset finished envs inside the step */
+
+/* outcome codes = settings.py:6 OUTCOME_NAMES */
+#define ACAS2D_OUTCOME_NONE 0
+#define ACAS2D_OUTCOME_GOAL 1
+#define ACAS2D_OUTCOME_COLLISION 2
+#define ACAS2D_OUTCOME_TIMEOUT 3
+
+/* Every tunable of gym_ACAS2D/settings.py:1-54 that the step path reads, plus the normalisers
+ * of game.py:120-128 and rewards.py:22-23,46-47 (constants under the reference's fixed start and
+ * goal).  Always float64 here; the f32 entry points round each field once on the host. */
+typedef struct Acas2dConfig {
+    double dt;               /* 1 / FPS                          aircraft.py:18        */
+    double acc_lat_limit;    /* ACC_LAT_LIMIT                    settings.py:42        */
+    int32_t max_steps;       /* MAX_STEPS                        settings.py:9         */
+    int32_t _pad;
+    double collision_dist;   /* 2 * COLLISION_RADIUS             game.py:187           */
+    double goal_radius;      /* GOAL_RADIUS                      game.py:192           */
+    double safe_distance;    /* SAFE_DISTANCE                    rewards.py:16         */
+    double d_goal_max;       /* obs normaliser                   game.py:120           */
+    double d_dev_max;        /* obs normaliser                   game.py:122           */
+    double d_sep_max;        /* obs normaliser                   game.py:124           */
+    double d_cpa_max;        /* obs normaliser                   game.py:126           */
+    double v_closing_max;    /* obs normaliser                   game.py:128           */
+    double rw_d_goal_max;    /* reward-side d_goal_max           rewards.py:46-47      */
+    double rw_d_dev_max;     /* reward-side d_dev_max            rewards.py:22-23      */
+    double reward_goal;      /* REWARD_GOAL                      settings.py:47        */
+    double reward_collision; /* REWARD_COLLISION                 settings.py:48        */
+    /* reset distribution, game.py:80-116 */
+    double own_x0, own_y0, own_v;       /* game.py:85-87                                */
+    double own_heading0;                /* relative_angle(start -> goal), game.py:91    */
+    double own_heading_jitter;          /* PLAYER_INITIAL_HEADING_LIM, settings.py:43   */
+    double goal_x, goal_y;              /* game.py:80-81                                */
+    double t0_x, t0_y_base, t0_y_span;  /* game.py:100-101                              */
+    double t0_heading_base, t0_heading_step, t0_heading_jitter; /* game.py:105-106      */
+    double tn_x_max, tn_y_max;          /* game.py:109-110                              */
+    double speed_factor_min, speed_factor_max, airspeed;        /* game.py:103,112      */
+} Acas2dConfig;
+
+/* Per-env state, device pointers (element type T = float for _f32, double for _f64). */
+typedef struct Acas2dState {
+    void *own_x, *own_y, *own_psi, *own_v;
+    void *goal_x, *goal_y;
+    void *trf_x, *trf_y, *trf_psi, *trf_v;
+    int32_t *steps;
+    void *total_reward;
+    uint8_t *status;
+    uint32_t *episode;
+} Acas2dState;
+
+/* Inputs / outputs of one step, device pointers.  term_obs, ep_return, ep_steps may be NULL. */
+typedef struct Acas2dStepIO {
+    const void *actions; /* T[E]      action[0] in [-1, 1]              game.py:225           */
+    void *obs;           /* T[E][D]   observe()                         game.py:194-220       */
+    void *reward;        /* T[E]      evaluate()                        game.py:249-292       */
+    uint8_t *done;       /* u8[E]     is_done()                         game.py:294-314       */
+    uint8_t *outcome;    /* u8[E]     game.outcome of THIS step (0 while running)             */
+    void *term_obs;      /* T[E][D]   AUTO_RESET: last obs of a finished episode (rows of
+                                      envs that did not finish are left untouched)            */
+    void *ep_return;     /* T[E]      AUTO_RESET: game.total_reward at done                   */
+    int32_t *ep_steps;   /* i32[E]    AUTO_RESET: game.steps at done (= step() calls + 1)     */
+} Acas2dStepIO;
+
+int acas2d_abi_version(void);
+size_t acas2d_config_size(void);      /* sizeof(Acas2dConfig): layout check for bindings */
+const char *acas2d_last_error(void);  /* thread-local; valid until the next failing call  */
+
+/*
+ * acas2d_step_*: replaces ACAS2DEnv.step(action) (environment.py:29-42) for n_envs independent
+ * envs: game.action -> game.observe -> game.evaluate -> game.is_done, one kernel launch.
+ *   flags & ACAS2D_AUTO_RESET: finished envs store term_obs/ep_return/ep_steps, bump episode[e],
+ *     are re-initialised with the distribution of game.py:80-116 from the counter-based RNG
+ *     Philox4x32-10(key = seed, counter = (env_offset + e, episode[e], entity)) and return the
+ *     new episode's first observation in obs (SB3 DummyVecEnv.step_wait semantics).
+ *   otherwise: status[e] latches the outcome; stepping a finished env keeps moving the player
+ *     but freezes its traffic (game.py:243-245).
+ * env_offset = global index of env 0 of this shard (results are invariant to the sharding).
+ */
+int acas2d_step_f32(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
+                    uint32_t flags, uint64_t seed, int64_t env_offset, int64_t n_envs,
+                    int32_t n_traffic, void *stream);
+int acas2d_step_f64(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
+                    uint32_t flags, uint64_t seed, int64_t env_offset, int64_t n_envs,
+                    int32_t n_traffic, void *stream);
+
+/*
+ * acas2d_reset_*: replaces ACAS2DEnv.reset() (environment.py:44-48 -> ACAS2DGame.__init__,
+ * game.py:28-41,80-116, then observe()).  For every env with mask[e] != 0 (mask == NULL: all):
+ *   do_init != 0: draw a fresh episode from the Philox stream described above
+ *                 (episode[e] is read, not modified), steps = 0, total_reward = 0, status = 0;
+ *   do_init == 0: keep the state the caller wrote into the buffers (oracle-state injection /
+ *                 host-side MT19937 "parity reset"), only zero total_reward and status;
+ * then, if obs != NULL, run observe(): steps += 1 and the first observation into obs[e].
+ */
+int acas2d_reset_f32(const Acas2dConfig *cfg, const Acas2dState *state, const uint8_t *mask,
+                     void *obs, int32_t do_init, uint64_t seed, int64_t env_offset,
+                     int64_t n_envs, int32_t n_traffic, void *stream);
+int acas2d_reset_f64(const Acas2dConfig *cfg, const Acas2dState *state, const uint8_t *mask,
+                     void *obs, int32_t do_init, uint64_t seed, int64_t env_offset,
+                     int64_t n_envs, int32_t n_traffic, void *stream);
+
+/*
+ * Launch geometry chosen for (n_envs, n_traffic): lanes per env (power of two <= 64), threads
+ * per workgroup and number of workgroups.  Informational (bench / DESIGN.md); returns 0.
+ */
+int acas2d_launch_geometry(int64_t n_envs, int32_t n_traffic, int32_t *lanes_per_env,
+                           int32_t *block_threads, int64_t *grid_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACAS2D_H */

@@ -1,0 +1,336 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the UNMODIFIED reference (/root/reference) into tests/golden/.
+
+TEST INFRASTRUCTURE ONLY -- runs in the build container (the reference never travels to the
+GPU box; only the .npz/.json data written here does).  Recipe follows SURVEY.md §8c:
+
+  * gym / pygame are replaced by the inert stubs of ``stubs.py`` (no arithmetic lives there);
+  * N_TRAFFIC != 1 is obtained by patching the star-import copies
+    ``game.MIN_TRAFFIC/MAX_TRAFFIC`` and ``environment.MAX_TRAFFIC`` (harness-side attributes,
+    reference files untouched);
+  * actions are float64 (NEP-50 trap), stdout is swallowed (game.py:311-313 prints on done),
+    the *global* ``random`` module is seeded.
+
+Outputs (all data, no code):
+  tests/golden/ref_rollout_n{N}.npz   random-action rollouts with reset-on-done, N in {1,3,8,64}
+  tests/golden/ref_edge_n{N}.npz      single steps from hand-placed states (thresholds, wrap, NaN)
+  tests/golden/ref_baseline_replay.npz  harness replay of baseline_main.simulate() (initial states
+                                      + outcomes; cross-checked against the reference's own CSV)
+  tests/golden/csv_baseline_digest.npz  digest of the reference's committed CSV
+                                      gym_ACAS2D/models/logs/baseline_ACAS2D_PPO_11_100.csv
+                                      (pure data transformation; needs no reference import)
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/refharness/capture_golden.py
+"""
+import ast
+import contextlib
+import csv
+import io
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("ACAS2D_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, HERE)
+sys.path.insert(0, REF)
+
+import stubs  # noqa: E402
+
+stubs.install()
+
+import gym_ACAS2D  # noqa: E402,F401
+import gym_ACAS2D.envs.environment as ref_environment  # noqa: E402
+import gym_ACAS2D.envs.game as ref_game  # noqa: E402
+from gym_ACAS2D.envs import ACAS2DEnv  # noqa: E402
+
+
+def set_n_traffic(n):
+    ref_game.MIN_TRAFFIC = ref_game.MAX_TRAFFIC = n
+    ref_environment.MAX_TRAFFIC = n
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        with np.errstate(all="ignore"):
+            yield
+
+
+def own_state(g):
+    p = g.player
+    return [float(p.x), float(p.y), float(p.psi), float(p.v_air)]
+
+
+def traffic_state(g):
+    return [[float(t.x), float(t.y), float(t.psi), float(t.v_air)] for t in g.traffic]
+
+
+# ---------------------------------------------------------------------------------------------
+def capture_rollout(n_traffic, n_steps, seed_py, seed_actions):
+    set_n_traffic(n_traffic)
+    random.seed(seed_py)
+    rng = np.random.default_rng(seed_actions)
+    with quiet():
+        env = ACAS2DEnv()            # consumes one game's worth of draws (constructor)
+        obs0 = env.reset()
+    ep_own, ep_trf, ep_goal, ep_obs0 = [], [], [], []
+
+    def new_episode(o):
+        g = env.game
+        ep_own.append(own_state(g))
+        ep_trf.append(traffic_state(g))
+        ep_goal.append([float(g.goal_x), float(g.goal_y)])
+        ep_obs0.append(np.asarray(o, dtype=np.float64))
+
+    new_episode(obs0)
+    rec = {k: [] for k in ("ep", "k", "action", "obs", "reward", "done", "outcome", "steps",
+                           "own", "trf_xy", "total_reward")}
+    k = 0
+    for _ in range(n_steps):
+        a = float(rng.uniform(-1.0, 1.0))
+        with quiet():
+            o, r, d, _info = env.step(np.array([a], dtype=np.float64))
+        g = env.game
+        rec["ep"].append(len(ep_own) - 1)
+        rec["k"].append(k)
+        rec["action"].append(a)
+        rec["obs"].append(np.asarray(o, dtype=np.float64))
+        rec["reward"].append(float(r))
+        rec["done"].append(bool(d))
+        rec["outcome"].append(0 if g.outcome is None else int(g.outcome))
+        rec["steps"].append(int(g.steps))
+        rec["own"].append(own_state(g)[:3])
+        rec["trf_xy"].append([[t.x, t.y] for t in g.traffic])
+        rec["total_reward"].append(float(g.total_reward))
+        k += 1
+        if d:
+            with quiet():
+                o = env.reset()
+            new_episode(o)
+            k = 0
+    out = dict(
+        n_traffic=np.int32(n_traffic), seed_py=np.int64(seed_py), seed_actions=np.int64(seed_actions),
+        ep_own=np.array(ep_own), ep_trf=np.array(ep_trf), ep_goal=np.array(ep_goal),
+        ep_obs0=np.array(ep_obs0),
+        ep=np.array(rec["ep"], np.int32), k=np.array(rec["k"], np.int32),
+        action=np.array(rec["action"]), obs=np.array(rec["obs"]), reward=np.array(rec["reward"]),
+        done=np.array(rec["done"], np.uint8), outcome=np.array(rec["outcome"], np.uint8),
+        steps=np.array(rec["steps"], np.int32), own=np.array(rec["own"]),
+        trf_xy=np.array(rec["trf_xy"]), total_reward=np.array(rec["total_reward"]),
+    )
+    path = os.path.join(OUT, "ref_rollout_n%d.npz" % n_traffic)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "episodes", len(ep_own), "steps", n_steps,
+          "dones", int(out["done"].sum()), "kB", os.path.getsize(path) // 1024)
+
+
+# ---------------------------------------------------------------------------------------------
+def edge_cases(n_traffic, rng):
+    """Hand-placed (own, traffic[], steps, action) tuples that hit every branch of the step."""
+    cases = []
+    gx, gy = 1456.0, 500.0
+
+    def rand_trf(n):
+        return [[rng.uniform(0, 1576), rng.uniform(0, 1000), rng.uniform(0, 360), 200.0] for _ in range(n)]
+
+    def add(own, trf, steps, action):
+        trf = [list(map(float, t)) for t in trf]
+        while len(trf) < n_traffic:
+            trf.append([rng.uniform(300, 1500), rng.uniform(0, 200), rng.uniform(0, 360), 200.0])
+        cases.append((list(map(float, own)), trf[:n_traffic], int(steps), float(action)))
+
+    # generic random mid-episode states
+    for _ in range(24):
+        add([rng.uniform(48, 1500), rng.uniform(100, 900), rng.uniform(0, 360), 200.0],
+            rand_trf(n_traffic), rng.integers(1, 990), rng.uniform(-1, 1))
+    # collision threshold: traffic[j] placed so that post-step distance straddles 96
+    for j in sorted({0, n_traffic - 1}):
+        for off in (-1e-3, -1e-9, 0.0, 1e-9, 1e-3, 5.0, -5.0):
+            own = [600.0, 500.0, 10.0, 200.0]
+            ang = rng.uniform(0, 2 * np.pi)
+            trf = [[rng.uniform(900, 1500), rng.uniform(0, 150), rng.uniform(0, 360), 200.0]
+                   for _ in range(n_traffic)]
+            trf[j] = [600.0 + (96.0 + off) * np.cos(ang), 500.0 + (96.0 + off) * np.sin(ang), 10.0, 200.0]
+            add(own, trf, 77, 0.0)       # same heading & speed => relative geometry is kept (d_cpa = NaN)
+            # crossing traffic: pre-step position chosen so the POST-step distance is 96 + off
+            psi_t = rng.uniform(0, 360)
+            ox = 600.0 + 2.0 * np.cos(np.deg2rad(10.0))
+            oy = 500.0 + 2.0 * np.sin(np.deg2rad(10.0))
+            trf = [list(t) for t in trf]
+            trf[j] = [ox + (96.0 + off) * np.cos(ang) - 2.0 * np.cos(np.deg2rad(psi_t)),
+                      oy + (96.0 + off) * np.sin(ang) - 2.0 * np.sin(np.deg2rad(psi_t)), psi_t, 200.0]
+            add(own, trf, 78, 0.0)
+    # goal threshold (144) with and without a simultaneous collision
+    for off in (-1e-3, -1e-9, 1e-9, 1e-3, 3.0, -3.0):
+        add([gx - 146.0 - off, gy, 0.0, 200.0], rand_trf(n_traffic), 400, 0.0)
+    add([gx - 140.0, gy + 3.0, 1.0, 200.0], [[gx - 100.0, gy, 180.0, 200.0]], 123, 0.3)   # goal + collision
+    # timeout boundary: steps is the value BEFORE observe() increments it (game.py:197, 182-183)
+    for s in (998, 999, 1000, 1001):
+        add([700.0, 480.0, 5.0, 200.0], rand_trf(n_traffic), s, -0.2)
+    add([gx - 140.0, gy, 0.0, 200.0], [[gx - 100.0, gy, 180.0, 200.0]], 1000, 0.0)   # all three at once
+    # heading wrap-around at 0/360, both directions, saturated actions
+    for psi, a in ((0.2, -1.0), (359.8, 1.0), (0.0, -1.0), (0.0, 1.0), (360.0, 0.0), (359.99999999, 1.0),
+                   (180.0, 1.0), (90.0, -1.0), (270.0, 0.5)):
+        add([500.0, 500.0, psi, 200.0], rand_trf(n_traffic), 10, a)
+    # parallel flight: identical heading => relative velocity 0/0 (NaN) or ~0 (kinematics.py:48)
+    add([400.0, 400.0, 45.0, 200.0], [[900.0, 300.0, 45.0, 200.0]], 50, 0.0)
+    add([400.0, 400.0, 90.0, 200.0], [[900.0, 300.0, 270.0, 200.0]], 50, 0.0)    # v12x ~ 0 -> atan(+-big)
+    add([400.0, 400.0, 0.0, 200.0], [[900.0, 400.0, 180.0, 200.0]], 50, 0.0)     # head-on, v12y ~ 0
+    add([400.0, 400.0, 0.0, 200.0], [[300.0, 400.0, 0.0, 200.0]], 50, 0.7)       # traffic behind
+    # far off-plan (|d_dev| > 704) and behind the start
+    add([700.0, 1300.0, 300.0, 200.0], rand_trf(n_traffic), 600, 0.1)
+    add([-150.0, 520.0, 180.0, 200.0], rand_trf(n_traffic), 300, -0.4)
+    # traffic faster/slower than the player (exercises the v_1 bug of kinematics.py:74)
+    add([500.0, 450.0, 20.0, 200.0], [[800.0, 300.0, 200.0, 260.0]], 20, 0.25)
+    add([500.0, 450.0, 340.0, 180.0], [[800.0, 700.0, 160.0, 140.0]], 20, -0.25)
+    return cases
+
+
+def capture_edges(n_traffic, seed):
+    set_n_traffic(n_traffic)
+    random.seed(seed)
+    rng = np.random.default_rng(seed)
+    cases = edge_cases(n_traffic, rng)
+    with quiet():
+        env = ACAS2DEnv()
+    rows = {k: [] for k in ("own", "trf", "steps", "action", "obs", "reward", "done", "outcome",
+                            "own_out", "trf_out", "steps_out")}
+    for own, trf, steps, action in cases:
+        with quiet():
+            env.reset()
+            g = env.game
+            g.player.x, g.player.y, g.player.psi, g.player.v_air = own
+            for t, s in zip(g.traffic, trf):
+                t.x, t.y, t.psi, t.v_air = s
+            g.steps = steps
+            o, r, d, _ = env.step(np.array([action], dtype=np.float64))
+        rows["own"].append(own)
+        rows["trf"].append(trf)
+        rows["steps"].append(steps)
+        rows["action"].append(action)
+        rows["obs"].append(np.asarray(o, np.float64))
+        rows["reward"].append(float(r))
+        rows["done"].append(bool(d))
+        rows["outcome"].append(0 if g.outcome is None else int(g.outcome))
+        rows["own_out"].append(own_state(g))
+        rows["trf_out"].append(traffic_state(g))
+        rows["steps_out"].append(int(g.steps))
+    out = dict(n_traffic=np.int32(n_traffic), goal=np.array([float(g.goal_x), float(g.goal_y)]),
+               own=np.array(rows["own"]), trf=np.array(rows["trf"]),
+               steps=np.array(rows["steps"], np.int32), action=np.array(rows["action"]),
+               obs=np.array(rows["obs"]), reward=np.array(rows["reward"]),
+               done=np.array(rows["done"], np.uint8), outcome=np.array(rows["outcome"], np.uint8),
+               own_out=np.array(rows["own_out"]), trf_out=np.array(rows["trf_out"]),
+               steps_out=np.array(rows["steps_out"], np.int32))
+    path = os.path.join(OUT, "ref_edge_n%d.npz" % n_traffic)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "cases", len(cases), "dones", int(out["done"].sum()),
+          "nan_obs_rows", int(np.isnan(out["obs"]).any(axis=1).sum()))
+
+
+# ---------------------------------------------------------------------------------------------
+CSV_PATH = os.path.join(REF, "gym_ACAS2D", "models", "logs", "baseline_ACAS2D_PPO_11_100.csv")
+OUTCOME_CODE = {"Goal": 1, "Collision": 2, "Timeout": 3}
+STRIDE = 50
+
+
+def csv_digest():
+    """Digest of the reference's own golden CSV (data only): outcome, steps, return, and every
+    50th + first two + last player / traffic[0] positions of each of the 100 episodes."""
+    csv.field_size_limit(1 << 30)
+    outcome, steps, ret, n_pts = [], [], [], []
+    own_first2, own_last, trf_first3, trf_last = [], [], [], []
+    own_sub = np.full((100, 1 + 1001 // STRIDE, 2), np.nan)
+    trf_sub = np.full((100, 1 + 1001 // STRIDE, 2), np.nan)
+    with open(CSV_PATH, newline="") as f:
+        for i, row in enumerate(csv.DictReader(f)):
+            path = np.array(ast.literal_eval(row["Path"]), dtype=np.float64)
+            tpath = np.array(ast.literal_eval(row["Traffic Paths"]), dtype=np.float64)[0]
+            outcome.append(OUTCOME_CODE[row["Outcome"]])
+            steps.append(int(row["Time Steps"]))
+            ret.append(float(row["Total Reward"]))
+            n_pts.append(len(path))
+            own_first2.append(path[:2])
+            own_last.append(path[-1])
+            trf_first3.append(tpath[:3])
+            trf_last.append(tpath[-1])
+            sub = path[::STRIDE]
+            own_sub[i, :len(sub)] = sub
+            sub = tpath[::STRIDE]
+            trf_sub[i, :len(sub)] = sub
+    out = dict(outcome=np.array(outcome, np.uint8), steps=np.array(steps, np.int32),
+               total_reward=np.array(ret), n_points=np.array(n_pts, np.int32),
+               own_first2=np.array(own_first2), own_last=np.array(own_last),
+               trf_first3=np.array(trf_first3), trf_last=np.array(trf_last),
+               own_sub=own_sub, trf_sub=trf_sub, stride=np.int32(STRIDE))
+    path = os.path.join(OUT, "csv_baseline_digest.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "goal/collision/timeout",
+          [(out["outcome"] == c).sum() for c in (1, 2, 3)], "mean return", out["total_reward"].mean(),
+          "mean steps", out["steps"].mean())
+    return out
+
+
+def baseline_replay(digest):
+    """baseline_main.simulate() through the harness: random.seed(13); ACAS2DEnv(); one reset()
+    (what SB3-1.1.0 check_env consumed); then 100 x (reset + step([0]) until done)."""
+    set_n_traffic(1)
+    random.seed(13)
+    with quiet():
+        env = ACAS2DEnv()
+        env.reset()
+    own0, trf0, outcome, steps, ret, own_last = [], [], [], [], [], []
+    exact_paths = 0
+    csv.field_size_limit(1 << 30)
+    with open(CSV_PATH, newline="") as f:
+        rows = list(csv.DictReader(f))
+    for ep in range(100):
+        with quiet():
+            env.reset()
+        g = env.game
+        own0.append(own_state(g))
+        trf0.append(traffic_state(g))
+        for _t in range(1000):
+            with quiet():
+                _o, _r, d, _ = env.step(np.array([0]))
+            if d:
+                break
+        g = env.game
+        outcome.append(int(g.outcome))
+        steps.append(int(g.steps))
+        ret.append(float(g.total_reward))
+        own_last.append([g.player.x, g.player.y])
+        ref_path = np.array(ast.literal_eval(rows[ep]["Path"]), dtype=np.float64)
+        ref_tpath = np.array(ast.literal_eval(rows[ep]["Traffic Paths"]), dtype=np.float64)[0]
+        exact_paths += int(np.array_equal(np.array(g.path), ref_path) and
+                           np.array_equal(np.array(g.traffic_paths[0]), ref_tpath))
+    outcome, steps, ret = np.array(outcome, np.uint8), np.array(steps, np.int32), np.array(ret)
+    report = dict(outcomes_equal=int((outcome == digest["outcome"]).sum()),
+                  steps_equal=int((steps == digest["steps"]).sum()),
+                  paths_bit_exact=exact_paths,
+                  returns_bit_exact=int((ret == digest["total_reward"]).sum()),
+                  max_abs_return_diff=float(np.abs(ret - digest["total_reward"]).max()))
+    print("harness vs reference CSV:", report)
+    assert report["outcomes_equal"] == 100 and report["steps_equal"] == 100 and exact_paths == 100
+    assert report["max_abs_return_diff"] < 1e-9
+    path = os.path.join(OUT, "ref_baseline_replay.npz")
+    np.savez_compressed(path, own0=np.array(own0), trf0=np.array(trf0), outcome=outcome, steps=steps,
+                        total_reward=ret, own_last=np.array(own_last),
+                        **{"report_" + k: np.array(v) for k, v in report.items()})
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    digest = csv_digest()
+    baseline_replay(digest)
+    for n, steps in ((1, 2500), (3, 1500), (8, 1000), (64, 160)):
+        capture_rollout(n, steps, seed_py=13 + n, seed_actions=n)
+        capture_edges(n, seed=100 + n)
