@@ -182,7 +182,10 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
     return c;
 }
 __device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
-__device__ __forceinline__ double uniform(double a, double b, double u) { return a + (b - a) * u; }
+__device__ __forceinline__ double uniform(double a, double b, double u) {
+#pragma clang fp contract(off)   // same rounding in the f32 (contract=fast) and f64 builds
+    return a + (b - a) * u;
+}
 
 // ---- one env's player, as every lane of its group sees it ------------------------------------------
 template <typename T>
@@ -274,6 +277,7 @@ template <typename T, int G>
 __device__ __forceinline__ Own<T> reset_env(const ResetParams& rp, const State<T>& s, uint32_t k0,
                                             uint32_t k1, uint64_t gid, uint32_t episode, int64_t e,
                                             int j, int N) {
+#pragma clang fp contract(off)   // float64 here in both builds: a seed names the same episode
     const uint32_t g_lo = (uint32_t)gid, g_hi = (uint32_t)(gid >> 32);
     U4 w = philox4x32_10(U4{g_lo, g_hi, episode, 0u}, k0, k1);
     Own<T> o;

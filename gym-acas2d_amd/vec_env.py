@@ -180,11 +180,12 @@ class ACAS2DVecEnv:
             self._launch_reset(m, do_init=1)
         return self._obs
 
-    def set_state(self, own, traffic, goal=None, steps=None):
+    def set_state(self, own, traffic, goal=None, steps=None, observe=True):
         """Inject state (oracle vectors / host parity reset): own [E,4] = (x, y, psi, v),
         traffic [E,N,4], goal [E,2] or [2] (default: the config's goal), steps [E] = game.steps
-        BEFORE the next observe().  Returns the observation observe() yields on that state
-        (which increments steps, game.py:197)."""
+        BEFORE the next observe().  With observe=True (what ACAS2DEnv.reset() does,
+        environment.py:47) returns the observation of that state and increments steps
+        (game.py:197); with observe=False the state is left exactly as given."""
         E, N = self.num_envs, self.n_traffic
         t = lambda a: torch.as_tensor(np.asarray(a), dtype=self.dtype).to(self.device)  # noqa: E731
         own, traffic = t(own).reshape(E, 4), t(traffic).reshape(E, N, 4)
@@ -201,8 +202,8 @@ class ACAS2DVecEnv:
                 self.steps.zero_()
             else:
                 self.steps.copy_(torch.as_tensor(np.asarray(steps), dtype=torch.int32).to(self.device).reshape(E))
-            self._launch_reset(None, do_init=0)
-        return self._obs
+            self._launch_reset(None, do_init=0, with_obs=observe)
+        return self._obs if observe else None
 
     def step_async(self, actions):
         """game.py:225 takes action[0] in [-1, 1]; accepts [E], [E,1], numpy or tensor."""

@@ -1,0 +1,409 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes ->
+libacas2d_hip.so), against the CPU oracle and the committed golden vectors.
+
+Tolerances (north star: masks bit-exact, 1e-5 abs on float positions / rewards):
+  float64 instantiation -- the parity gate.  Asserted far tighter than required: 1e-9 abs on
+      positions, observations, rewards and returns over full episodes; done / outcome / step
+      masks bit-exact (cases placed within 1e-9 of a threshold excepted and counted).
+  float32 instantiation -- throughput mode.  float32 cannot REPRESENT 1600-px positions or
+      +-1000 rewards to 1e-5 (ulp(1024..2048) = 1.2e-4, ulp(1000) = 6.1e-5), so single steps from
+      identical (float32-representable) states are held to: observations 1e-5 abs (2e-5 for the
+      signed d_cpa entry), non-terminal rewards 1e-5 abs, positions / terminal rewards 1 float32
+      ulp (1.3e-4); masks exact outside a 1e-3 band around the thresholds.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gym_acas2d_amd as g
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    g.native.lib()          # fails loudly if the HIP extension is missing
+    return g
+
+
+@pytest.fixture(scope="module")
+def O(oracle_mod):
+    return oracle_mod
+
+
+class GpuEngine:
+    """The HIP path behind the OracleEnvs interface (numpy float64 views), see helpers.py."""
+
+    def __init__(self, g, E, N, dtype=None, auto_reset=False, seed=13, env_offset=0):
+        self.v = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype or torch.float64,
+                                auto_reset=auto_reset, seed=seed, env_offset=env_offset)
+        self.E, self.N = E, N
+
+    @staticmethod
+    def _np(t):
+        return t.detach().cpu().numpy().astype(np.float64) if t.is_floating_point() else t.detach().cpu().numpy()
+
+    def __getattr__(self, name):
+        if name in ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y",
+                    "trf_psi", "trf_v", "steps", "total_reward", "status"):
+            return self._np(getattr(self.v, name))
+        if name == "episode":
+            return self.v.episode.cpu().numpy().view(np.uint32)
+        if name in ("term_obs", "ep_return", "ep_steps"):
+            key = {"term_obs": "terminal_observation", "ep_return": "episode_return",
+                   "ep_steps": "episode_steps"}[name]
+            return self._np(self.v.outputs[key])
+        raise AttributeError(name)
+
+    def set_state(self, own, trf, goal=None, steps=None):
+        self.v.set_state(own, trf, goal, steps, observe=False)
+
+    def observe(self):
+        # observe() on the state as it stands: re-inject it with observe=True
+        st = np.stack([self.own_x, self.own_y, self.own_psi, self.own_v], 1)
+        tr = np.stack([self.trf_x, self.trf_y, self.trf_psi, self.trf_v], -1)
+        go = np.stack([self.goal_x, self.goal_y], 1)
+        return self._np(self.v.set_state(st, tr, go, self.steps, observe=True))
+
+    def reset(self):
+        return self._np(self.v.reset())
+
+    def step(self, actions):
+        obs, rew, done, _ = self.v.step(np.asarray(actions, np.float64))
+        out = self.v.outputs
+        d = done.cpu().numpy().astype(np.uint8)
+        return self._np(obs), self._np(rew), d, out["outcome"].cpu().numpy(), int(d.sum())
+
+
+def grazing(fx_obs, N, cfg, band):
+    """Rows whose post-step geometry lies within `band` of a collision / goal threshold."""
+    d_sep = fx_obs[:, 5::3][:, :N] * cfg.d_sep_max
+    d_goal = fx_obs[:, 3] * cfg.d_goal_max
+    with np.errstate(invalid="ignore"):
+        return (np.abs(d_sep - cfg.collision_dist) < band).any(1) | (np.abs(d_goal - cfg.goal_radius) < band)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", (1, 3, 8, 64))
+def test_f64_edge_vectors(g, O, N):
+    fx = H.load("ref_edge_n%d.npz" % N)
+    E = len(fx["action"])
+    env = GpuEngine(g, E, N)
+    env.set_state(fx["own"], fx["trf"], fx["goal"], fx["steps"])
+    obs, reward, done, outcome, _ = env.step(fx["action"])
+    assert np.array_equal(np.isnan(obs), np.isnan(fx["obs"]))
+    np.testing.assert_allclose(obs, fx["obs"], rtol=0, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(reward, fx["reward"], rtol=0, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(np.stack([env.own_x, env.own_y, env.own_psi, env.own_v], 1),
+                               fx["own_out"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.stack([env.trf_x, env.trf_y, env.trf_psi, env.trf_v], -1),
+                               fx["trf_out"], rtol=0, atol=1e-9)
+    assert np.array_equal(env.steps, fx["steps_out"])
+    cfgc = O.default_config()
+    ok = ~grazing(fx["obs"], N, cfgc, 1e-9)
+    assert ok.sum() >= E - 12
+    assert np.array_equal(done[ok], fx["done"][ok]) and np.array_equal(outcome[ok], fx["outcome"][ok])
+    assert np.array_equal(env.status[ok], fx["outcome"][ok])        # latched (auto_reset off)
+
+
+@pytest.mark.parametrize("N", (1, 3, 8, 64))
+def test_f64_reference_rollouts(g, N):
+    fx = H.load("ref_rollout_n%d.npz" % N)
+    n_ep = len(fx["ep_own"])
+    env = GpuEngine(g, n_ep, N)
+    env.set_state(fx["ep_own"], fx["ep_trf"], fx["ep_goal"], np.zeros(n_ep, np.int32))
+    np.testing.assert_allclose(env.observe(), fx["ep_obs0"], rtol=0, atol=1e-9)
+    res = H.replay_rollout(env, fx)
+    assert res["n"] == len(fx["action"])
+    assert res["done_mismatch"] == 0 and res["outcome_mismatch"] == 0 and res["steps_mismatch"] == 0
+    assert res["pos"] < 1e-9 and res["psi"] < 1e-9 and res["obs"] < 1e-9
+    assert res["reward"] < 1e-9 and res["total_reward"] < 1e-8
+
+
+def test_f64_reference_csv_baseline(g):
+    """The reference's own golden CSV replayed on the GPU (100 constant-action episodes)."""
+    dg = H.load("csv_baseline_digest.npz")
+    cfg = g.ACAS2DConfig(n_traffic=1)
+    own, trf, goal = H.parity_reset_states(cfg, 13, 2, 100)
+    env = GpuEngine(g, 100, 1)
+    env.set_state(own, trf, goal, np.zeros(100, np.int32))
+    env.observe()
+    out = H.replay_baseline(env, dg, own, trf)
+    assert out["unfinished"] == 0
+    assert np.array_equal(out["outcome"], dg["outcome"]) and np.array_equal(out["steps"], dg["steps"])
+    for k in ("own_sub", "trf_sub", "own_first2", "own_last"):
+        np.testing.assert_allclose(out[k], dg[k], rtol=0, atol=1e-9, equal_nan=True)
+    assert np.abs(out["total_reward"] - dg["total_reward"]).max() < 1e-8
+
+
+def test_single_env_adapter_reference_surface(g):
+    """ACAS2DEnv: random.seed(13) names the reference's episodes, old gym
+    4-tuple API, numpy float64, env.game.* attributes, CSV episode 1 end to end."""
+    import random
+    random.seed(13)
+    env = g.ACAS2DEnv()
+    obs = env.reset()
+    assert obs.dtype == np.float64 and obs.shape == (8,) and env.observation_space.shape == (8,)
+    assert env.action_space.shape == (1,)
+    p, t = env.game.player, env.game.traffic[0]
+    assert (p.x, p.y, p.v_air) == (48, 500.0, 200) and p.psi == 358.1242450086868
+    assert (t.x, t.y, t.v_air) == (1552, 48, 200.0) and t.psi == 136.41722591475224
+    want = [0.001, 0.99478957, 0., 0.41314554, 0., 0.26677536, 0.08703283, -0.92934645]
+    np.testing.assert_allclose(obs, want, atol=1e-8)
+    env.reset()                                 # third game after the seed = CSV episode 1
+    total, n = 0.0, 0
+    for _ in range(1000):
+        o, r, d, info = env.step(np.array([0]))
+        assert isinstance(r, float) and isinstance(d, bool) and info == {}
+        total += r
+        n += 1
+        if n == 1:
+            assert abs(env.game.path[-1][0] - 49.998468716044925) < 1e-11
+            assert abs(env.game.path[-1][1] - 499.92175173490904) < 1e-11
+        if d:
+            break
+    assert env.game.outcome == 2 and g.OUTCOME_NAMES[env.game.outcome] == "Collision"
+    assert env.game.steps == 390
+    assert abs(env.game.total_reward - (-988.6418379569138)) < 1e-8 and abs(total - env.game.total_reward) < 1e-9
+    assert len(env.game.path) == 390 and len(env.game.traffic_paths[0]) == 390
+    assert env.game.traffic_paths[0][1] == env.game.traffic_paths[0][0]      # appendix A quirk
+    # stepping a finished env: player moves, traffic frozen (game.py:243-245)
+    t_before = (env.game.traffic[0].x, env.game.traffic[0].y)
+    env.step(np.array([0.0]))
+    assert (env.game.traffic[0].x, env.game.traffic[0].y) == t_before
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", (1, 3, 8, 64))
+def test_f32_single_step_vs_f64_oracle(g, O, N):
+    fx = H.load("ref_edge_n%d.npz" % N)
+    sel = ~np.isnan(fx["obs"]).any(1)
+    own = fx["own"][sel].astype(np.float32).astype(np.float64)        # float32-representable inputs
+    trf = fx["trf"][sel].astype(np.float32).astype(np.float64)
+    act = fx["action"][sel].astype(np.float32).astype(np.float64)
+    E = len(act)
+    ref = O.OracleEnvs(E, N)
+    ref.set_state(own, trf, fx["goal"], fx["steps"][sel])
+    o, r, d, oc, _ = ref.step(act)
+    env = GpuEngine(g, E, N, dtype=torch.float32)
+    env.set_state(own, trf, fx["goal"], fx["steps"][sel])
+    obs, rew, done, outcome, _ = env.step(act)
+    cfgc = O.default_config()
+    ok = ~grazing(o, N, cfgc, 1e-3)
+    assert ok.sum() >= E - 30
+    assert np.array_equal(done[ok], d[ok]) and np.array_equal(outcome[ok], oc[ok])
+    col = np.arange(o.shape[1])
+    cpa = (col >= 5) & ((col - 5) % 3 == 1)
+    assert np.abs(obs[:, ~cpa] - o[:, ~cpa]).max() < 1e-5
+    assert np.abs(obs[:, cpa] - o[:, cpa]).max() < 2e-5
+    term = d.astype(bool)
+    assert np.abs(rew[ok & ~term] - r[ok & ~term]).max() < 1e-5
+    assert np.abs(rew[ok & term] - r[ok & term]).max() <= 1.3e-4          # 1 ulp of float32(1000)
+    pos_err = max(np.abs(env.own_x - ref.own_x).max(), np.abs(env.own_y - ref.own_y).max(),
+                  np.abs(env.trf_x - ref.trf_x).max(), np.abs(env.trf_y - ref.trf_y).max())
+    assert pos_err <= 1.3e-4                                             # 1 ulp of float32(1600)
+    assert np.abs(env.own_psi - ref.own_psi).max() <= 3.1e-5             # 1 ulp of float32(360)
+
+
+@pytest.mark.parametrize("N", (1, 8))
+def test_f32_full_episodes_vs_f64_oracle(g, O, N):
+    """Whole episodes in float32 against the float64 oracle on the same actions: rounding
+    accumulates (<= ~0.1 px over 1000 steps), so outcomes / lengths may differ only for episodes
+    that cross a threshold within that margin.  Reported, and bounded at 2 %."""
+    E, T = 512, 1001
+    cfg = g.ACAS2DConfig(n_traffic=N)
+    own, trf, goal = H.parity_reset_states(cfg, 4242, 0, E)
+    rng = np.random.default_rng(5)
+    ref = O.OracleEnvs(E, N)
+    ref.set_state(own, trf, goal, np.zeros(E, np.int32))
+    ref.observe()
+    env = GpuEngine(g, E, N, dtype=torch.float32)
+    env.set_state(own, trf, goal, np.zeros(E, np.int32))
+    env.observe()
+    fin_r, fin_g = np.zeros(E, np.int32), np.zeros(E, np.int32)
+    oc_r, oc_g = np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+    max_pos = 0.0
+    for k in range(T):
+        a = rng.uniform(-1, 1, E).astype(np.float32).astype(np.float64)
+        _, _, d1, o1, _ = ref.step(a)
+        _, _, d2, o2, _ = env.step(a)
+        new = (fin_r == 0) & (d1 != 0)
+        fin_r[new], oc_r[new] = k + 1, o1[new]
+        new = (fin_g == 0) & (d2 != 0)
+        fin_g[new], oc_g[new] = k + 1, o2[new]
+        both = (fin_r == 0) & (fin_g == 0)
+        if both.any():
+            max_pos = max(max_pos, float(np.abs(env.own_x - ref.own_x)[both].max()),
+                          float(np.abs(env.own_y - ref.own_y)[both].max()))
+        if (fin_r > 0).all() and (fin_g > 0).all():
+            break
+    agree = (fin_r == fin_g) & (oc_r == oc_g)
+    print("f32 vs f64 episodes N=%d: %d/%d agree, max |dpos| while both running %.3g px" %
+          (N, agree.sum(), E, max_pos))
+    assert (fin_r > 0).all() and (fin_g > 0).all()
+    assert agree.mean() >= 0.98
+    assert np.abs(fin_r - fin_g).max() <= 2 or agree.mean() >= 0.98
+    assert max_pos < 0.25
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,E,T", ((3, 4096, 60), (8, 2048, 200), (64, 512, 40), (1, 1000, 30), (100, 96, 12)))
+def test_f64_auto_reset_vs_oracle(g, O, N, E, T):
+    """VecEnv semantics and the device Philox reset against the oracle, env-for-env: same seed
+    => same episodes, bit-exact reset states, terminal obs / returns / lengths, episode counters."""
+    ref = O.OracleEnvs(E, N, seed=99, env_offset=1000, auto_reset=True)
+    env = GpuEngine(g, E, N, auto_reset=True, seed=99, env_offset=1000)
+    o_ref, o_gpu = ref.reset(), env.reset()
+    for name in ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi", "trf_v"):
+        assert np.array_equal(getattr(env, name), getattr(ref, name)), name     # reset: bit-exact
+    np.testing.assert_allclose(o_gpu, o_ref, rtol=0, atol=1e-9)
+    rng = np.random.default_rng(1)
+    dones = 0
+    for _ in range(T):
+        a = rng.uniform(-1, 1, E)
+        o1, r1, d1, oc1, n1 = ref.step(a)
+        o2, r2, d2, oc2, n2 = env.step(a)
+        assert np.array_equal(d1, d2) and np.array_equal(oc1, oc2)
+        np.testing.assert_allclose(o2, o1, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(r2, r1, rtol=0, atol=1e-9)
+        assert np.array_equal(env.steps, ref.steps) and np.array_equal(env.episode, ref.episode)
+        d = d1.astype(bool)
+        if d.any():
+            dones += int(d.sum())
+            np.testing.assert_allclose(env.term_obs[d], ref.term_obs[d], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(env.ep_return[d], ref.ep_return[d], rtol=0, atol=1e-8)
+            assert np.array_equal(env.ep_steps[d], ref.ep_steps[d])
+            assert np.array_equal(env.trf_psi[d], ref.trf_psi[d]) and np.array_equal(env.own_psi[d], ref.own_psi[d])
+        np.testing.assert_allclose(env.total_reward, ref.total_reward, rtol=0, atol=1e-8)
+    assert dones > 0
+
+
+def test_f32_reset_names_the_same_episodes(g, O):
+    """float32 reset = float64 reset rounded once (same seed -> same episodes in both modes)."""
+    E, N = 4096, 8
+    ref = O.OracleEnvs(E, N, seed=5, auto_reset=True)
+    ref.reset()
+    env = GpuEngine(g, E, N, dtype=torch.float32, auto_reset=True, seed=5)
+    env.reset()
+    for name in ("own_psi", "trf_x", "trf_y", "trf_psi", "trf_v"):
+        assert np.array_equal(getattr(env, name), getattr(ref, name).astype(np.float32).astype(np.float64)), name
+
+
+def test_lazy_infos_and_vecenv_surface(g):
+    E, N = 256, 64                          # N = 64: episodes last ~8 steps -> many dones
+    env = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, seed=3)
+    obs = env.reset()
+    assert obs.shape == (E, 5 + 3 * N) and env.observation_space.shape == (5 + 3 * N,)
+    assert env.num_envs == E and env.env_is_wrapped(None) == [False] * E
+    seen = 0
+    for _ in range(10):
+        obs, rew, done, infos = env.step(torch.zeros(E, 1, device="cuda:0"))
+        assert obs.shape == (E, 5 + 3 * N) and rew.shape == (E,) and done.dtype == torch.bool
+        assert len(infos) == E
+        dn = done.cpu().numpy()
+        for i in np.nonzero(dn)[0][:5]:
+            info = infos[int(i)]
+            assert set(info) == {"outcome", "episode", "terminal_observation"}
+            assert info["episode"]["l"] == info["episode"]["steps"] - 1 >= 1
+            assert info["terminal_observation"].shape == (5 + 3 * N,)
+            assert info["outcome"] in (1, 2, 3)
+            seen += 1
+        for i in np.nonzero(~dn)[0][:3]:
+            assert infos[int(i)] == {}
+    assert seen > 0
+    sd = env.state_dict()
+    env.step(torch.zeros(E, device="cuda:0"))
+    env.load_state_dict(sd)
+    assert torch.equal(env.own_x, sd["own_x"])
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(E + 1, device="cuda:0"))
+
+
+# ---- BASELINE.json full sizes: oracle spot check + size-independent properties -------------------
+@pytest.mark.parametrize("E,N,T", ((65536, 8, 12), (131072, 8, 6), (65536, 64, 6), (4096, 3, 40)))
+def test_full_size_f64_vs_oracle(g, O, E, N, T):
+    ref = O.OracleEnvs(E, N, seed=13, auto_reset=True)
+    env = GpuEngine(g, E, N, auto_reset=True, seed=13)
+    ref.reset()
+    env.reset()
+    rng = np.random.default_rng(2)
+    for _ in range(T):
+        a = rng.uniform(-1, 1, E)
+        o1, r1, d1, oc1, _ = ref.step(a)
+        o2, r2, d2, oc2, _ = env.step(a)
+        assert np.array_equal(d1, d2) and np.array_equal(oc1, oc2)
+        assert np.abs(o2 - o1).max() < 1e-9 and np.abs(r2 - r1).max() < 1e-9
+    assert np.array_equal(env.steps, ref.steps) and np.array_equal(env.episode, ref.episode)
+
+
+@pytest.mark.parametrize("dtype_name", ("float32", "float64"))
+def test_full_size_properties(g, dtype_name):
+    """65 536 envs x 8 traffic (headline config): invariants every step, bitwise determinism,
+    and invariance to sharding (2 shards with env_offset == 1 shard)."""
+    dtype = getattr(torch, dtype_name)
+    E, N, T = 65536, 8, 40
+    dev = "cuda:0"
+    full = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13)
+    again = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13)
+    a_sh = g.ACAS2DVecEnv(40000, N, device=dev, dtype=dtype, seed=13, env_offset=0)
+    b_sh = g.ACAS2DVecEnv(E - 40000, N, device=dev, dtype=dtype, seed=13, env_offset=40000)
+    for e in (full, again, a_sh, b_sh):
+        e.reset()
+    gen = torch.Generator(device=dev).manual_seed(0)
+    prev_steps = full.steps.clone()
+    total_done = 0
+    for _ in range(T):
+        a = torch.rand(E, generator=gen, device=dev, dtype=dtype) * 2 - 1
+        obs, rew, done, infos = full.step(a)
+        o2, r2, d2, _ = again.step(a)
+        oa, ra, da, _ = a_sh.step(a[:40000].contiguous())
+        ob, rb, db, _ = b_sh.step(a[40000:].contiguous())
+        assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(done, d2)
+        assert torch.equal(obs, torch.cat([oa, ob])) and torch.equal(rew, torch.cat([ra, rb]))
+        assert torch.equal(done, torch.cat([da, db]))
+        steps = full.steps
+        # steps advance by one, or restart at 1 exactly where done
+        assert torch.equal(torch.where(done, torch.ones_like(steps), prev_steps + 1), steps)
+        assert torch.equal(done, infos.outcome > 0)
+        assert torch.equal(obs[:, 0], steps.to(dtype) / 1000)
+        psi = full.own_psi
+        assert bool(((psi >= 0) & (psi <= 360)).all())
+        assert bool(torch.isfinite(obs[:, [0, 1, 2, 3, 4]]).all()) and bool(torch.isfinite(rew).all())
+        assert bool((obs[:, 5::3] >= 0).all())                                  # distances
+        # a finished env collected the terminal bonus that its outcome implies
+        oc = infos.outcome
+        assert bool((rew[oc == 2] < -900).all()) and bool((rew[oc == 1] > 900).all())
+        assert bool((rew[~done].abs() <= 1.0 + 1e-6).all())
+        total_done += int(done.sum())
+        prev_steps = steps.clone()
+    assert total_done > 0
+
+
+def test_idempotent_observe_and_linearity_of_motion(g):
+    """Size-independent physics properties at 1 M envs: with action 0 every aircraft moves
+    exactly v*dt = 2 px per step along its heading, headings are unchanged, and re-observing a
+    state does not change it (observe() only increments the step counter)."""
+    E, N = 1 << 20, 8
+    env = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float64, seed=21, auto_reset=False)
+    env.reset()
+    x0, y0, psi0 = env.own_x.clone(), env.own_y.clone(), env.own_psi.clone()
+    tx0, ty0, tpsi0 = env.trf_x.clone(), env.trf_y.clone(), env.trf_psi.clone()
+    env.step(torch.zeros(E, dtype=torch.float64, device="cuda:0"))
+    live = env.status == 0
+    d_own = torch.hypot(env.own_x - x0, env.own_y - y0)
+    d_trf = torch.hypot(env.trf_x - tx0, env.trf_y - ty0)
+    assert float((d_own - 2.0).abs().max()) < 1e-9 and float((d_trf - 2.0).abs().max()) < 1e-9
+    assert torch.equal(env.own_psi, psi0) and torch.equal(env.trf_psi, tpsi0)
+    rad = torch.deg2rad(psi0)
+    assert float((env.own_x - x0 - 2 * torch.cos(rad)).abs().max()) < 1e-9
+    assert int(live.sum()) > 0
+
+
+def test_c_abi_rejects_bad_arguments_on_gpu_box(g):
+    import ctypes as C
+    L = g.native.lib()
+    assert L.acas2d_step_f32(None, None, None, 0, 0, 0, 16, 1, None) == -22
+    assert b"NULL" in L.acas2d_last_error()

@@ -1,0 +1,210 @@
+"""CPU tests (-m "not gpu"): the oracle against every golden vector there is for this path.
+
+  * the reference's own CSV  models/logs/baseline_ACAS2D_PPO_11_100.csv  (digest fixture),
+  * known answers printed in the reference's notebooks/rewards.ipynb,
+  * vectors captured from the unmodified reference (oracle/refharness/capture_golden.py),
+  * Random123's published Philox4x32-10 known-answer vectors (the build-defined reset RNG).
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+
+N_LIST = (1, 3, 8, 64)
+
+
+@pytest.fixture(scope="module")
+def O(oracle_mod):
+    return oracle_mod
+
+
+def test_philox_known_answers(O):
+    # Random123 kat_vectors, philox4x32 10 rounds
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert list(O.philox4x32_10(ctr, key)) == want
+
+
+def test_notebook_known_answers(O):
+    L = O.lib()
+    # notebooks/rewards.ipynb cell 18 (heading_reward, phi = 0): constants-independent
+    for psi, want in ((0, 1.0), (10, 0.7956199512269471), (350, 0.7956199512269471),
+                      (20, 0.624295076969974), (340, 0.624295076969974), (30, 0.4822530864197532),
+                      (330, 0.4822530864197532), (40, 0.3659503124523701), (320, 0.3659503124523701)):
+        assert L.acas2d_oracle_heading_reward(psi, 0.0) == pytest.approx(want, rel=0, abs=2e-16)
+    # cell 23 (closest_approach_reward(-1, k * SAFE_DISTANCE / 4)): SAFE_DISTANCE cancels
+    S = 192.0
+    for d, want in ((0, 0.0), (S / 4, 0.00390625), (-S / 4, 0.00390625), (S / 2, 0.0625), (-S / 2, 0.0625),
+                    (3 * S / 4, 0.31640625), (-3 * S / 4, 0.31640625), (S, 1), (-S, 1)):
+        assert L.acas2d_oracle_closest_approach_reward(-1.0, d, S) == want
+    assert L.acas2d_oracle_closest_approach_reward(10.0, S - 10, S) == 1
+    # cells 11 / 28 were produced with the notebook's stale kernel constants
+    # (d_goal_init = 856, d_goal_max = 2296.0, COLLISION/GOAL/SAFE = 48/96/192):
+    # valid as parametric known answers
+    for d, want in ((0, 1), (48, 0.9189622950516945), (96, 0.8429526657055691),
+                    (192, 0.7051725641148902), (2296.0, 0.0)):
+        assert L.acas2d_oracle_goal_distance_reward(d, 2296.0) == pytest.approx(want, rel=0, abs=2e-16)
+    for d, want in ((0, 1.0), (48, 0.9422581744350746), (-48, 0.9422581744350746),
+                    (96, 0.8807388571985678), (-96, 0.8807388571985678), (192, 0.7425643872142526),
+                    (856 / 4, 0.7071067811865476), (-856 / 4, 0.7071067811865476),
+                    (856 / 3, 0.5773502691896258), (856 / 2, 0.0), (-856 / 2, 0.0), (500, 0.0)):
+        assert L.acas2d_oracle_plan_deviation_reward(d, 428.0) == pytest.approx(want, rel=0, abs=2e-16)
+
+
+def test_l1_kinematics(O):
+    L = O.lib()
+    assert L.acas2d_oracle_distance(0, 0, 3, 4) == 5.0
+    assert L.acas2d_oracle_relative_angle(0, 0, 1, 0) == 0.0
+    assert L.acas2d_oracle_relative_angle(0, 0, 0, 1) == pytest.approx(90.0, abs=1e-13)
+    assert L.acas2d_oracle_relative_angle(0, 0, 0, -1) == pytest.approx(270.0, abs=1e-13)
+    assert L.acas2d_oracle_relative_angle(0, 0, -1, -0.0) == pytest.approx(180.0, abs=1e-13)
+    assert L.acas2d_oracle_delta_heading(350.0, 10.0) == 20.0
+    assert L.acas2d_oracle_delta_heading(10.0, 200.0) == 170.0
+
+
+@pytest.mark.parametrize("N", N_LIST)
+def test_single_step_edge_vectors(O, N):
+    """Hand-placed states through ONE reference step: thresholds (96 / 144 / 1000), heading wrap,
+    0/0 relative velocity (NaN d_cpa), off-plan, unequal airspeeds (kinematics.py:74 quirk)."""
+    fx = H.load("ref_edge_n%d.npz" % N)
+    E = len(fx["action"])
+    env = O.OracleEnvs(E, N)
+    env.set_state(fx["own"], fx["trf"], fx["goal"], fx["steps"])
+    obs, reward, done, outcome, _ = env.step(fx["action"])
+    assert np.array_equal(np.isnan(obs), np.isnan(fx["obs"]))
+    # bit-exact except d_cpa = d * sin(a_rel - arctan(.)): np.arctan is NumPy's own (<= 1 ulp
+    # from glibc's atan in ~0.1 % of arguments), seen through the sine as a few 1e-16 absolute
+    # (and closing speed: OpenBLAS ddot picks fma(a1,b1,a0*b0) or fma(a0,b0,a1*b1) depending on
+    # the alignment of NumPy's temporaries -- a handful of 1-ulp cases at N = 64)
+    col = np.arange(obs.shape[1])
+    exact = (col < 5) | ((col - 5) % 3 == 0)
+    assert np.array_equal(obs[:, exact], fx["obs"][:, exact], equal_nan=True)
+    np.testing.assert_allclose(obs, fx["obs"], rtol=0, atol=1e-15, equal_nan=True)
+    np.testing.assert_allclose(reward, fx["reward"], rtol=1e-14, atol=1e-15, equal_nan=True)
+    assert np.array_equal(done, fx["done"])
+    assert np.array_equal(outcome, fx["outcome"])
+    assert np.array_equal(env.steps, fx["steps_out"])
+    own = np.stack([env.own_x, env.own_y, env.own_psi, env.own_v], 1)
+    assert np.array_equal(own, fx["own_out"])
+    trf = np.stack([env.trf_x, env.trf_y, env.trf_psi, env.trf_v], -1)
+    assert np.array_equal(trf, fx["trf_out"])
+    assert done.sum() >= 15 and (outcome == 3).sum() >= 2 and (outcome == 2).sum() >= 4 and (outcome == 1).sum() >= 1
+
+
+@pytest.mark.parametrize("N", N_LIST)
+def test_reference_rollouts(O, N):
+    """Random-action rollouts captured from the reference; initial states from the host parity
+    reset (same MT19937 draws) must equal the captured ones, then every step must agree."""
+    import gym_acas2d_amd as g
+    fx = H.load("ref_rollout_n%d.npz" % N)
+    cfg = g.ACAS2DConfig(n_traffic=N)
+    n_ep = len(fx["ep_own"])
+    own, trf, goal = H.parity_reset_states(cfg, int(fx["seed_py"]), 1, n_ep)
+    assert np.array_equal(own, fx["ep_own"]) and np.array_equal(trf, fx["ep_trf"])
+    assert np.array_equal(goal, fx["ep_goal"])
+    env = O.OracleEnvs(n_ep, N)
+    env.set_state(own, trf, goal, np.zeros(n_ep, np.int32))
+    np.testing.assert_allclose(env.observe(), fx["ep_obs0"], rtol=0, atol=1e-15)
+    res = H.replay_rollout(env, fx)
+    assert res["n"] == len(fx["action"])
+    assert res["pos"] == 0.0 and res["psi"] == 0.0          # libm-only path: bit-exact
+    assert res["done_mismatch"] == 0 and res["outcome_mismatch"] == 0 and res["steps_mismatch"] == 0
+    assert res["obs"] < 1e-15 and res["reward"] < 1e-14 and res["total_reward"] < 1e-11
+
+
+def test_reference_csv_baseline(O):
+    """The reference's own golden file: 100 constant-action episodes (baseline_main.py).
+    Recipe: random.seed(13); one game for ACAS2DEnv(); one for check_env's
+    reset(); then the 100 episodes."""
+    import gym_acas2d_amd as g
+    dg = H.load("csv_baseline_digest.npz")
+    cfg = g.ACAS2DConfig(n_traffic=1)
+    own, trf, goal = H.parity_reset_states(cfg, 13, 2, 100)
+    rp = H.load("ref_baseline_replay.npz")
+    assert np.array_equal(own, rp["own0"]) and np.array_equal(trf, rp["trf0"])
+    env = O.OracleEnvs(100, 1)
+    env.set_state(own, trf, goal, np.zeros(100, np.int32))
+    env.observe()
+    out = H.replay_baseline(env, dg, own, trf)
+    assert out["unfinished"] == 0
+    assert np.array_equal(out["outcome"], dg["outcome"])
+    assert np.array_equal(out["steps"], dg["steps"])
+    assert (out["outcome"] == 1).sum() == 42 and (out["outcome"] == 2).sum() == 58   # notebook :280
+    # every 50th + first two + last positions of all 100 paths: bit-exact
+    assert np.array_equal(out["own_sub"], dg["own_sub"], equal_nan=True)
+    assert np.array_equal(out["trf_sub"], dg["trf_sub"], equal_nan=True)
+    assert np.array_equal(out["own_first2"], dg["own_first2"])
+    assert np.array_equal(out["own_last"], dg["own_last"])
+    # returns: the CSV was written by Python 3.7 on another machine; 98/100 are bit-exact here
+    assert np.abs(out["total_reward"] - dg["total_reward"]).max() < 1e-9
+    assert (out["total_reward"] == dg["total_reward"]).sum() >= 95
+    assert out["total_reward"].mean() == pytest.approx(-70.775011, abs=1e-6)        # notebook :280
+    assert out["steps"].mean() == pytest.approx(494.65)
+
+
+def test_step_after_done_freezes_traffic(O):
+    """game.py:243-245: a finished single env keeps moving the player but not the traffic."""
+    fx = H.load("ref_edge_n1.npz")
+    i = int(np.nonzero(fx["done"])[0][0])
+    env = O.OracleEnvs(1, 1)
+    env.set_state(fx["own"][i:i + 1], fx["trf"][i:i + 1], fx["goal"], fx["steps"][i:i + 1])
+    env.step(fx["action"][i:i + 1])
+    assert env.status[0] == fx["outcome"][i]
+    t0, p0 = (env.trf_x[0, 0], env.trf_y[0, 0]), (env.own_x[0], env.own_y[0])
+    env.step(np.zeros(1))
+    assert (env.trf_x[0, 0], env.trf_y[0, 0]) == t0 and (env.own_x[0], env.own_y[0]) != p0
+
+
+def test_auto_reset_semantics_and_reset_distribution(O):
+    """Build-defined VecEnv semantics of the oracle (the GPU path is compared against these):
+    finished envs report terminal obs / return / steps and restart from the Philox stream with
+    the reference's reset distribution (game.py:80-116)."""
+    N, E = 8, 512
+    env = O.OracleEnvs(E, N, seed=13, auto_reset=True)
+    env.reset()
+    c = env.cfg
+    assert np.all(env.own_x == 48) and np.all(env.own_y == 500) and np.all(env.goal_x == 1456)
+    psi = env.own_psi
+    assert np.all((psi < 3) | (psi > 357))
+    assert set(np.unique(env.trf_y[:, 0])) == {48.0, 952.0} and np.all(env.trf_x[:, 0] == 1552)
+    down = env.trf_y[:, 0] > 500
+    h0 = env.trf_psi[:, 0]
+    assert np.all(np.abs(h0[~down] - 145) <= 15) and np.all(np.abs(h0[down] - 215) <= 15)
+    assert 0.35 < down.mean() < 0.65
+    assert env.trf_x[:, 1:].min() >= 0 and env.trf_x[:, 1:].max() <= 1576
+    assert env.trf_y[:, 1:].min() >= 0 and env.trf_y[:, 1:].max() <= 600
+    assert abs(env.trf_x[:, 1:].mean() - 788) < 40 and abs(env.trf_psi[:, 1:].mean() - 180) < 10
+    assert np.all(env.trf_v == 200) and np.all(env.steps == 1)
+    rng = np.random.default_rng(0)
+    seen = 0
+    for _ in range(60):
+        ep_before = env.episode.copy()
+        obs, r, done, oc, n = env.step(rng.uniform(-1, 1, E))
+        d = done.astype(bool)
+        seen += int(n)
+        assert n == d.sum()
+        assert np.array_equal(env.episode, ep_before + d)
+        assert np.all(env.steps[d] == 1) and np.all(env.total_reward[d] == 0)
+        assert np.all(obs[d, 0] == 1 / 1000) and np.all(env.term_obs[d, 0] > 1 / 1000)
+        assert np.all(env.ep_steps[d] >= 2)
+        assert np.all(oc[~d] == 0) and np.all(oc[d] > 0)
+    assert seen > 20
+
+
+def test_sharding_invariance_of_reset_stream(O):
+    """Episodes depend on (seed, global env index, episode counter) only."""
+    N = 3
+    full = O.OracleEnvs(64, N, seed=7, auto_reset=True)
+    full.reset()
+    a = O.OracleEnvs(40, N, seed=7, env_offset=0, auto_reset=True)
+    b = O.OracleEnvs(24, N, seed=7, env_offset=40, auto_reset=True)
+    a.reset()
+    b.reset()
+    assert np.array_equal(np.concatenate([a.trf_psi, b.trf_psi]), full.trf_psi)
+    assert np.array_equal(np.concatenate([a.own_psi, b.own_psi]), full.own_psi)
+    other = O.OracleEnvs(64, N, seed=8, auto_reset=True)
+    other.reset()
+    assert not np.array_equal(other.own_psi, full.own_psi)
