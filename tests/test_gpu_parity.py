@@ -198,7 +198,15 @@ def test_f32_single_step_vs_f64_oracle(g, O, N):
     col = np.arange(o.shape[1])
     cpa = (col >= 5) & ((col - 5) % 3 == 1)
     assert np.abs(obs[:, ~cpa] - o[:, ~cpa]).max() < 1e-5
-    assert np.abs(obs[:, cpa] - o[:, cpa]).max() < 2e-5
+    # d_cpa = d * sin(a_rel - arctan(v12y / v12x)) (kinematics.py:48-49) jumps by +-2 d when the
+    # relative velocity's x component changes sign: entries with |v12x| < 0.02 px/s (of 200) are
+    # ill-conditioned in the reference itself and excluded -- counted, they are a handful
+    rad = np.deg2rad
+    v12x = (ref.own_v * np.cos(rad(ref.own_psi)))[:, None] - ref.trf_v * np.cos(rad(ref.trf_psi))
+    well = np.abs(v12x) > 0.02
+    assert (~well).sum() <= 4
+    assert np.abs(obs[:, cpa] - o[:, cpa])[well].max() < 2e-5
+    ok &= well[:, 0]                                  # the reward reads traffic[0]'s d_cpa
     term = d.astype(bool)
     assert np.abs(rew[ok & ~term] - r[ok & ~term]).max() < 1e-5
     assert np.abs(rew[ok & term] - r[ok & term]).max() <= 1.3e-4          # 1 ulp of float32(1000)
@@ -382,10 +390,9 @@ def test_full_size_properties(g, dtype_name):
     assert total_done > 0
 
 
-def test_idempotent_observe_and_linearity_of_motion(g):
+def test_linearity_of_motion_at_one_million_envs(g):
     """Size-independent physics properties at 1 M envs: with action 0 every aircraft moves
-    exactly v*dt = 2 px per step along its heading, headings are unchanged, and re-observing a
-    state does not change it (observe() only increments the step counter)."""
+    exactly v*dt = 2 px per step along its heading and headings are unchanged."""
     E, N = 1 << 20, 8
     env = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float64, seed=21, auto_reset=False)
     env.reset()
