@@ -47,6 +47,7 @@ def parse():
                     help="replay the step launches from a captured hipGraph (default) or launch eagerly")
     ap.add_argument("--chunk", type=int, default=100, help="steps per captured graph / action rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic: latch outcomes instead of resetting")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -102,7 +103,8 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     E, N, K, W = args.envs, args.traffic, args.steps, args.warmup
 
-    env = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13, env_offset=rank * E)
+    env = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13, env_offset=rank * E,
+                         auto_reset=not args.no_auto_reset)
     env.reset()
     chunk = max(1, min(args.chunk, K))
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -157,7 +159,7 @@ def main():
         bytes_per_launch = E * g.ACAS2DConfig.algorithmic_bytes_per_env_step(N, s)
         launch_us = dev_ms * 1e3 / K
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-        geo = g.native.launch_geometry(E, N)
+        geo = g.native.launch_geometry(E, N, s)
         out = {
             "metric": "env-steps/sec at 65536 envs x N_TRAFFIC=8; achieved HBM GB/s vs peak",
             "value": E * world * K / wall,
@@ -172,12 +174,14 @@ def main():
             "config": {"workload": "%d envs x N_TRAFFIC=%d per GPU, %s, one step-kernel launch per step(), "
                                    "auto-reset on, random actions U(-1,1)" % (E, N, args.dtype),
                        "envs_per_gpu": E, "n_traffic": N, "launch": args.launch,
-                       "lanes_per_env": geo["lanes_per_env"], "grid_blocks": geo["grid_blocks"],
+                       "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"],
+                       "grid_blocks": geo["grid_blocks"],
                        "parallelism": "env-index shards x%d, no collective on the step path" % world,
                        "episodes_finished": int(episodes)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(E, N, args.dtype),
-                         "kernel": "acas2d::step_kernel<%s,%d,true>" % ("float" if s == 4 else "double", geo["lanes_per_env"]),
+                         "kernel": "acas2d::step_kernel<%s, C=%d, G=%d>" % ("float" if s == 4 else "double",
+                                                                            geo["traffic_per_lane"], geo["lanes_per_env"]),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launch_us": launch_us},
         }

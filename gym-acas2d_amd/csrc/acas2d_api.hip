@@ -15,13 +15,22 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// lanes per env: the power of two >= n_traffic, capped at one wave (64); more than 64 traffic
-// aircraft are walked in strides of 64 by the same lanes.
-int lanes_per_env(int n_traffic) {
-    int g = 1;
-    while (g < n_traffic && g < 64) g <<= 1;
-    return g;
+// Default work shape for (n_traffic, element size): packed (C traffic per lane as one 16-byte
+// vector, G = N / C lanes per env) where N tiles that way, else the generic strided walk with
+// G in {1, 4, 16, 64} lanes per env.  Tuned on MI355X.
+Shape choose_shape(int n, int elem_size) {
+    const int c16 = 16 / elem_size;                       // values per 16-byte vector
+    if (n == 2) return Shape{2, 1, true};
+    if (n == 3) return Shape{3, 1, true};
+    if (n % c16 == 0) {
+        const int g = n / c16;
+        if (g <= 64 && (g & (g - 1)) == 0) return Shape{c16, g, true};
+    }
+    return Shape{1, n >= 64 ? 64 : (n >= 16 ? 16 : (n >= 4 ? 4 : 1)), false};
 }
+
+template <typename T>
+int shape_geometry(int64_t n_envs, int32_t n_traffic, int32_t* lanes, int32_t* per_lane, int64_t* grid);
 
 }  // namespace acas2d
 
@@ -52,13 +61,19 @@ int acas2d_reset_f64(const Acas2dConfig* cfg, const Acas2dState* state, const ui
     return launch_reset<double>(cfg, state, mask, obs, do_init, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
 }
 
-int acas2d_launch_geometry(int64_t n_envs, int32_t n_traffic, int32_t* lanes, int32_t* block_threads,
-                           int64_t* grid_blocks) {
-    if (n_traffic < 1 || n_envs < 0) { set_error("acas2d_launch_geometry: bad sizes"); return ACAS2D_EINVAL; }
-    const int g = lanes_per_env(n_traffic);
-    if (lanes) *lanes = g;
+int acas2d_launch_geometry(int64_t n_envs, int32_t n_traffic, int32_t elem_size, int32_t* lanes_per_env,
+                           int32_t* traffic_per_lane, int32_t* block_threads, int64_t* grid_blocks) {
+    if (n_traffic < 1 || n_envs < 0 || (elem_size != 4 && elem_size != 8)) {
+        set_error("acas2d_launch_geometry: bad sizes"); return ACAS2D_EINVAL; }
+    int32_t g = 0, c = 0;
+    int64_t grid = 0;
+    const int rc = elem_size == 4 ? shape_geometry<float>(n_envs, n_traffic, &g, &c, &grid)
+                                  : shape_geometry<double>(n_envs, n_traffic, &g, &c, &grid);
+    if (rc) return rc;
+    if (lanes_per_env) *lanes_per_env = g;
+    if (traffic_per_lane) *traffic_per_lane = c;
     if (block_threads) *block_threads = kBlock;
-    if (grid_blocks) *grid_blocks = (n_envs * g + kBlock - 1) / kBlock;
+    if (grid_blocks) *grid_blocks = grid;
     return ACAS2D_OK;
 }
 

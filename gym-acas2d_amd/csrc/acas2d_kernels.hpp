@@ -1,19 +1,33 @@
 // acas2d_kernels.hpp -- CDNA4 (gfx950) device code of the batched ACAS2D step engine.
 //
 // One launch advances every env by one ACAS2DEnv.step() (reference: gym_ACAS2D/envs/
-// environment.py:29-42).  Work decomposition: an env is owned by a GROUP of G consecutive lanes
-// (G = power of two, 1..64, chosen from n_traffic on the host); lane j of the group owns traffic
-// aircraft j, j+G, ...  With the env-major traffic block  trf_*[E][N]  a wave's loads and stores
-// of the traffic block are fully coalesced (lane-linear addresses), the per-env scalars are
-// same-address broadcasts, and the only cross-lane traffic is a log2(G)-step reduce of the
-// collision predicate plus one broadcast of traffic[0]'s closing speed / d_cpa for the reward.
+// environment.py:29-42).
+//
+// Work decomposition.  An env is owned by a GROUP of G consecutive lanes (G = power of two,
+// 1..64); lane j of the group owns C traffic aircraft:
+//   packed  (N == C*G): the contiguous run [jC, jC+C) of the env's traffic block, moved with one
+//           16-byte (C*sizeof(T)) vector load / store per state field -- lane-linear addresses,
+//           1 KiB per wave-instruction, the coalescing sweet spot of the HBM path;
+//   generic (any N, C = 1): traffic j, j+G, j+2G, ... with dword accesses.
+// The traffic block is env-major, trf_*[E][N], so one env's block is contiguous.  Per-env
+// scalars are same-address broadcast loads.  Observations are staged in a per-wavefront LDS tile
+// (rows of D = 5+3N values, exactly the wave's contiguous slice of obs[E][D]) and flushed with
+// lane-linear 16-byte stores; the tile also feeds terminal_observation on auto-reset.  The only
+// cross-lane traffic is a log2(G)-step OR-reduce of the collision predicate (min-distance < 96)
+// and one broadcast of traffic[0]'s closing speed / d_cpa for the reward.
 //
 // The path is HBM-bound by design (no dense contraction -> no MFMA): B(N, s) = s(16 + 9N) + 9
 // algorithmic bytes per env-step.
 //
-// Arithmetic follows the reference's operation order (cited per function) so that the float64
-// instantiation agrees with the CPU reference to rounding of the device libm; the float32
-// instantiation is the throughput mode.
+// Two formulations of the same arithmetic, selected at compile time:
+//   EXACT (float64 build)  the reference's operation order, literally, with device libm --
+//          agrees with the CPU reference to ~1e-13;
+//   FAST  (float32 build)  algebraically identical, fewer roundings and no libm calls:
+//          d_dev = goal_y - y (= d_goal sin(atan2(dy, dx))), d_cpa = sign(v12x) (dy v12x - dx v12y)
+//          / |v12| (= d sin(a_rel - arctan(v12y / v12x)), incl. the sign quirk of the plain
+//          arctan), headings handled in revolutions so that v_sin_f32 / v_cos_f32 (1.3e-7 abs,
+//          measured) need no range reduction, atan2 as a degree-15 odd minimax polynomial
+//          (2.6e-8 rev), divisions by constants as multiplications, v_rcp / v_rsq / v_sqrt.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -24,6 +38,22 @@
 namespace acas2d {
 
 constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+// In-kernel stamps: DIAGNOSTIC build only (tools/diag_stamps.py builds libacas2d_hip_diag.so with
+// -DACAS2D_STAMPS).  In the product build ACAS2D_STAMP() is empty and no stamp executes.
+#ifdef ACAS2D_STAMPS
+static __device__ unsigned long long* g_stamps = nullptr;   // [n_waves][8], set by acas2d_debug_set_stamps_*
+#define ACAS2D_STAMP(k, wave_id, lane_id, drain)                                              \
+    do {                                                                                      \
+        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
+        if ((lane_id) == 0 && g_stamps)                                                       \
+            g_stamps[(wave_id) * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() \
+                                                                   : __builtin_amdgcn_s_memtime();    \
+    } while (0)
+#else
+#define ACAS2D_STAMP(k, wave_id, lane_id, drain) do { } while (0)
+#endif
 
 // ---- launch-constant parameters, already rounded to T on the host -----------------------------
 template <typename T>
@@ -31,8 +61,29 @@ struct Params {
     T dt, acc_lat_limit, collision_dist, goal_radius, safe_distance;
     T d_goal_max, d_dev_max, d_sep_max, d_cpa_max, v_closing_max;
     T rw_d_goal_max, rw_d_dev_max, reward_goal, reward_collision;
+    // reciprocals for the FAST formulation
+    T inv_dt, inv_d_goal_max, inv_d_dev_max, inv_d_sep_max, inv_d_cpa_max, inv_v_closing_max;
+    T inv_rw_d_goal_max, inv_rw_d_dev_max, inv_safe_distance, inv_max_steps;
     int32_t max_steps;
 };
+
+// Kernel arguments live in the kernarg segment; under SGPR pressure hipcc re-fetches them with
+// s_load + s_waitcnt lgkmcnt(0) at every use (8+ full scalar-cache round trips in the step
+// kernel's main path, each also draining the LDS queue).  Pinning the launch constants into
+// VGPRs once at kernel entry removes every one of those stalls.
+template <typename T>
+__device__ __forceinline__ void pin_vgpr(T& x) { asm volatile("" : "+v"(x)); }
+template <typename T>
+__device__ __forceinline__ Params<T> pinned(Params<T> p) {
+    pin_vgpr(p.dt); pin_vgpr(p.acc_lat_limit); pin_vgpr(p.collision_dist); pin_vgpr(p.goal_radius);
+    pin_vgpr(p.safe_distance); pin_vgpr(p.d_goal_max); pin_vgpr(p.d_dev_max); pin_vgpr(p.d_sep_max);
+    pin_vgpr(p.d_cpa_max); pin_vgpr(p.v_closing_max); pin_vgpr(p.rw_d_goal_max); pin_vgpr(p.rw_d_dev_max);
+    pin_vgpr(p.reward_goal); pin_vgpr(p.reward_collision); pin_vgpr(p.inv_dt); pin_vgpr(p.inv_d_goal_max);
+    pin_vgpr(p.inv_d_dev_max); pin_vgpr(p.inv_d_sep_max); pin_vgpr(p.inv_d_cpa_max);
+    pin_vgpr(p.inv_v_closing_max); pin_vgpr(p.inv_rw_d_goal_max); pin_vgpr(p.inv_rw_d_dev_max);
+    pin_vgpr(p.inv_safe_distance); pin_vgpr(p.inv_max_steps);
+    return p;
+}
 
 // reset distribution (game.py:80-116); evaluated in float64 for both instantiations so that a
 // seed names the same episode in f32 and f64, then rounded to T once.
@@ -78,15 +129,33 @@ __device__ __forceinline__ float m_fma(float a, float b, float c) { return fmaf(
 __device__ __forceinline__ double m_fma(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ float m_fmod(float a, float b) { return fmodf(a, b); }
 __device__ __forceinline__ double m_fmod(double a, double b) { return fmod(a, b); }
+__device__ __forceinline__ float m_copysign(float a, float b) { return copysignf(a, b); }
+__device__ __forceinline__ double m_copysign(double a, double b) { return copysign(a, b); }
+
+// hardware fast paths (FAST formulation; the double overloads keep FAST usable for T = double)
+__device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double f_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float f_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double f_rsq(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double f_sqrt(double x) { return sqrt(x); }
+// sin / cos of an angle given in REVOLUTIONS (v_sin_f32 / v_cos_f32 compute sin(2 pi x))
+__device__ __forceinline__ void f_sincos_rev(float r, float* s, float* c) {
+    *s = __builtin_amdgcn_sinf(r);
+    *c = __builtin_amdgcn_cosf(r);
+}
+__device__ __forceinline__ void f_sincos_rev(double r, double* s, double* c) {
+    sincos(r * 6.28318530717958647692, s, c);
+}
 
 template <typename T> struct Const;
 template <> struct Const<float> {
     static constexpr float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f,
-                           rad2deg = 57.29577951308232087680f;
+                           rad2deg = 57.29577951308232087680f, inv360 = 1.0f / 360.0f;
 };
 template <> struct Const<double> {
     static constexpr double pi = 3.14159265358979323846, two_pi = 6.28318530717958647692,
-                            rad2deg = 57.29577951308232087680;
+                            rad2deg = 57.29577951308232087680, inv360 = 1.0 / 360.0;
 };
 
 // Python float `a % 360` (CPython float_rem == NumPy remainder): sign of the divisor.
@@ -95,11 +164,15 @@ template <> struct Const<double> {
 template <typename T>
 __device__ __forceinline__ T py_mod360(T a) {
     const T m = T(360);
-    if (a >= T(0) && a < m) return a;
-    if (a >= m && a < T(720)) return a - m;
-    if (a < T(0) && a > -m) return a + m;          // fmod(a, 360) == a, then += 360
-    T r = m_fmod(a, m);                             // general case (and NaN)
-    if (r != T(0)) { if (r < T(0)) r += m; } else { r = T(0); }
+    // common window, branch-free and exact: [0,360) -> a; [360,720) -> a - 360 (Sterbenz);
+    // (-360,0) -> fmod(a,360) == a, then += 360 exactly as CPython does
+    T r = a;
+    r = (a >= m) ? a - m : r;
+    r = (a < T(0)) ? a + m : r;
+    if (__builtin_expect(!(a > -m && a < T(720)), 0)) {   // injected headings / NaN only
+        r = m_fmod(a, m);
+        if (r != T(0)) { if (r < T(0)) r += m; } else { r = T(0); }
+    }
     return r;
 }
 
@@ -123,6 +196,31 @@ __device__ __forceinline__ T relative_angle(T x1, T y1, T x2, T y2) {
     return r * Const<T>::rad2deg;
 }
 
+// FAST: atan2(y, x) mod 2 pi, in REVOLUTIONS [0, 1].  Octant reduction + odd minimax polynomial
+// of degree 15 for atan(t) / (2 pi), t in [0, 1] (max error 2.6e-8 rev = 9.4e-6 degrees in
+// float32, fitted offline).  atan2(+-0, +-0) = 0 like C; y = -0 never counts as negative, which
+// reproduces `atan2 % (2 pi)` mapping -0.0 to +0.0.
+template <typename T>
+__device__ __forceinline__ T atan2_rev(T y, T x) {
+    const T ax = m_abs(x), ay = m_abs(y);
+    const T mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const T t = (mx == T(0)) ? T(0) : mn * f_rcp(mx);
+    const T u = t * t;
+    T p = T(-6.4530050760e-04);
+    p = m_fma(p, u, T(3.4795833267e-03));
+    p = m_fma(p, u, T(-8.8987017304e-03));
+    p = m_fma(p, u, T(1.5346017534e-02));
+    p = m_fma(p, u, T(-2.2136264969e-02));
+    p = m_fma(p, u, T(3.1745943883e-02));
+    p = m_fma(p, u, T(-5.3046120845e-02));
+    p = m_fma(p, u, T(1.5915483734e-01));
+    p = p * t;
+    if (ay > ax) p = T(0.25) - p;
+    if (x < T(0)) p = T(0.5) - p;
+    if (y < T(0)) p = T(1) - p;
+    return p;
+}
+
 // kinematics.py:82-83  builtin min(a, b) -> b only if b < a
 template <typename T>
 __device__ __forceinline__ T delta_heading(T psi, T phi) {
@@ -134,17 +232,28 @@ template <typename T> __device__ __forceinline__ T pow4(T x) { T x2 = x * x; ret
 template <typename T> __device__ __forceinline__ T py_min1(T v) { return (v < T(1)) ? v : T(1); }
 
 // rewards.py:53-60 step_reward_5 with :5-9, :12-16, :19-27, :44-50 inlined.
-template <typename T>
+template <typename T, bool FAST>
 __device__ __forceinline__ T step_reward_5(const Params<T>& p, T v_closing, T psi, T phi, T d_cpa,
                                             T d_goal, T d_dev) {
-    T hr = pow4(T(1) - delta_heading(psi, phi) / T(180));
-    if (v_closing <= T(0)) {
-        T car = py_min1(pow4(d_cpa / p.safe_distance));
-        T ad = m_abs(d_dev);
-        T pdr = (ad > p.rw_d_dev_max) ? T(0) : m_sqrt(T(1) - ad / p.rw_d_dev_max);
-        return hr * car * pdr;
+    if constexpr (FAST) {
+        T hr = pow4(T(1) - delta_heading(psi, phi) * T(1.0 / 180.0));
+        if (v_closing <= T(0)) {
+            T car = py_min1(pow4(d_cpa * p.inv_safe_distance));
+            T ad = m_abs(d_dev);
+            T pdr = (ad > p.rw_d_dev_max) ? T(0) : f_sqrt(T(1) - ad * p.inv_rw_d_dev_max);
+            return hr * car * pdr;
+        }
+        return hr * py_min1(pow4(T(1) - d_goal * p.inv_rw_d_goal_max));
+    } else {
+        T hr = pow4(T(1) - delta_heading(psi, phi) / T(180));
+        if (v_closing <= T(0)) {
+            T car = py_min1(pow4(d_cpa / p.safe_distance));
+            T ad = m_abs(d_dev);
+            T pdr = (ad > p.rw_d_dev_max) ? T(0) : m_sqrt(T(1) - ad / p.rw_d_dev_max);
+            return hr * car * pdr;
+        }
+        return hr * py_min1(pow4(T(1) - d_goal / p.rw_d_goal_max));
     }
-    return hr * py_min1(pow4(T(1) - d_goal / p.rw_d_goal_max));
 }
 
 // ---- cross-lane helpers within a group of G lanes ------------------------------------------------
@@ -158,6 +267,14 @@ template <int G, typename T>
 __device__ __forceinline__ T group_bcast0(T v) {
     if constexpr (G == 1) return v;
     return __shfl(v, (int)(threadIdx.x & 63u) & ~(G - 1), 64);
+}
+
+// Orders this wave's LDS writes before its later LDS reads (the tile is private to the wave and
+// a wave's DS instructions execute in issue order, so only the COMPILER must be held back).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // XCD-aware block remap: blocks are dealt round-robin over the 8 XCDs, so give each XCD one
@@ -174,9 +291,8 @@ struct U4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c.x), l0 = 0xD2511F53u * c.x;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c.z), l1 = 0xCD9E8D57u * c.z;
-        c = U4{h1 ^ c.y ^ k0, l1, h0 ^ c.w ^ k1, l0};
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;   // v_mad_u64_u32
+        c = U4{(uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0};
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return c;
@@ -187,10 +303,25 @@ __device__ __forceinline__ double uniform(double a, double b, double u) {
     return a + (b - a) * u;
 }
 
+// ---- per-lane vector of C traffic values ---------------------------------------------------------
+template <typename T, int C>
+struct alignas((C * sizeof(T)) % 16 == 0 ? 16 : ((C * sizeof(T)) % 8 == 0 ? 8 : sizeof(T))) Vec {
+    T v[C];
+};
+
 // ---- one env's player, as every lane of its group sees it ------------------------------------------
 template <typename T>
 struct Own {
     T x, y, psi, v, a_lat, gx, gy;
+};
+
+// Player-side terms shared by every traffic aircraft of the env.
+template <typename T>
+struct OwnCtx {
+    T x, y, v;
+    T co, so;             // cos / sin of the player's heading                (kinematics.py:35-36)
+    T v1x, v1y, x1, y1;   // closing_speed(): one-step-ahead projection        (kinematics.py:56-65)
+    T d_goal, h_goal, d_dev;
 };
 
 // What the reward / termination need back from observe().
@@ -200,86 +331,217 @@ struct Seen {
     int collided;
 };
 
-// game.py:194-220 observe() (+ the traffic half of game.py:222-247 action() when MOVE is set):
-// every lane computes the player-side terms (same-address inputs, identical results), lane j
-// walks traffic j, j+G, ... and writes its three observation entries.  `steps` is the already
-// incremented counter.
-template <typename T, int G>
-__device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
-                                           int64_t e, int j, int N, int32_t steps, bool move,
-                                           T* __restrict__ obs_row) {
-    Seen<T> r;
-    // relative_speed() player terms, kinematics.py:27-29,35-36
-    T so, co;
-    m_sincos(deg2rad_ref(o.psi), &so, &co);
-    // closing_speed() player projection, kinematics.py:56-65 (psi_dot = a_lat / v: no /dt here)
-    T psi1 = py_mod360(o.psi + ((o.a_lat / o.v) * p.dt));
-    T s1, c1;
-    m_sincos(deg2rad_ref(psi1), &s1, &c1);
-    T v1x = (o.v * c1) * p.dt, v1y = (o.v * s1) * p.dt;
-    T x1 = o.x + v1x, y1 = o.y + v1y;
-    // game.py:168-180
-    r.d_goal = distance(o.x, o.y, o.gx, o.gy);
-    r.h_goal = relative_angle(o.x, o.y, o.gx, o.gy);
-    r.d_dev = r.d_goal * m_sin(deg2rad_ref(r.h_goal));
+template <typename T, bool FAST>
+__device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T>& o) {
+    OwnCtx<T> c;
+    c.x = o.x; c.y = o.y; c.v = o.v;
+    if constexpr (FAST) {
+        f_sincos_rev(o.psi * Const<T>::inv360, &c.so, &c.co);
+        T psi1 = py_mod360(o.psi + (o.a_lat * f_rcp(o.v)) * p.dt);
+        T s1, c1;
+        f_sincos_rev(psi1 * Const<T>::inv360, &s1, &c1);
+        const T vdt = o.v * p.dt;
+        c.v1x = vdt * c1; c.v1y = vdt * s1;
+        c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
+        const T gdx = o.gx - o.x, gdy = o.gy - o.y;
+        c.d_goal = f_sqrt(m_fma(gdy, gdy, gdx * gdx));
+        c.h_goal = atan2_rev(gdy, gdx) * T(360);
+        c.d_dev = gdy;            // d_goal * sin(atan2(gdy, gdx)) == gdy          (game.py:175-180)
+    } else {
+        m_sincos(deg2rad_ref(o.psi), &c.so, &c.co);
+        // psi_dot = a_lat / v: no /dt here, unlike aircraft.py:20
+        T psi1 = py_mod360(o.psi + ((o.a_lat / o.v) * p.dt));
+        T s1, c1;
+        m_sincos(deg2rad_ref(psi1), &s1, &c1);
+        c.v1x = (o.v * c1) * p.dt; c.v1y = (o.v * s1) * p.dt;
+        c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
+        c.d_goal = distance(o.x, o.y, o.gx, o.gy);                                // game.py:168-169
+        c.h_goal = relative_angle(o.x, o.y, o.gx, o.gy);                          // game.py:171-173
+        c.d_dev = c.d_goal * m_sin(deg2rad_ref(c.h_goal));                        // game.py:175-180
+    }
+    return c;
+}
 
-    int coll = 0;
-    T vc0 = T(0), dc0 = T(0);
-    for (int n = j; n < N; n += G) {
-        const int64_t i = e * N + n;
-        T tx = s.trf_x[i], ty = s.trf_y[i], tpsi = s.trf_psi[i], tv = s.trf_v[i];
-        // aircraft.py:16-26 with a_lat = 0: psi = psi % 360, then the Euler step
-        T tpsi_w = py_mod360(tpsi);
-        T st, ct;
-        m_sincos(deg2rad_ref(tpsi_w), &st, &ct);
+// One traffic aircraft: the traffic half of game.py:222-247 action() (when `move`) and the raw
+// (un-normalised) values behind its three observation entries of game.py:205-210.
+// In/out: tx, ty (moved), tpsi (wrapped).
+template <typename T, bool FAST>
+__device__ __forceinline__ void traffic_step(const Params<T>& p, const OwnCtx<T>& c, bool move, T& tx,
+                                             T& ty, T& tpsi, T tv, T& d, T& dca, T& vc) {
+    // aircraft.py:16-26 with a_lat = 0: psi = psi % 360, then the Euler step
+    tpsi = py_mod360(tpsi);
+    T st, ct;
+    if constexpr (FAST) {
+        f_sincos_rev(tpsi * Const<T>::inv360, &st, &ct);
+        const T tvdt = tv * p.dt;
+        const T v2x = tvdt * ct, v2yt = tvdt * st;
+        if (move) { tx += v2x; ty += v2yt; }
+        const T dx = tx - c.x, dy = ty - c.y;
+        d = f_sqrt(m_fma(dy, dy, dx * dx));
+        // kinematics.py:40-49: d sin(a_rel - arctan(v12y / v12x))
+        //   == sign(v12x) (dy v12x - dx v12y) / |v12|   (sign bit of v12x, so -0.0 counts as
+        //   negative like the quotient's; v12 == 0 gives 0 * inf = NaN like the reference's 0/0)
+        const T v12x = m_fma(c.v, c.co, -(tv * ct)), v12y = m_fma(c.v, c.so, -(tv * st));
+        const T cross = m_fma(dy, v12x, -(dx * v12y));
+        dca = (m_copysign(T(1), v12x) * cross) * f_rsq(m_fma(v12y, v12y, v12x * v12x));
+        // kinematics.py:52-79; v2.y uses the PLAYER's airspeed (:74), kept
+        const T v2y = (c.v * p.dt) * st;
+        const T x2 = tx + v2x, y2 = ty + v2yt;
+        const T ax = c.v1x - v2x, ay = c.v1y - v2y, bx = c.x1 - x2, by = c.y1 - y2;
+        vc = (m_fma(ay, by, ax * bx) * f_rsq(m_fma(by, by, bx * bx))) * p.inv_dt;
+    } else {
+        m_sincos(deg2rad_ref(tpsi), &st, &ct);
         if (move) {
             tx = tx + ((tv * ct) * p.dt);
             ty = ty + ((tv * st) * p.dt);
-            s.trf_x[i] = tx;
-            s.trf_y[i] = ty;
-            if (tpsi_w != tpsi) s.trf_psi[i] = tpsi_w;   // only ever for injected headings >= 360
         }
-        // game.py:205-210
-        T d = distance(o.x, o.y, tx, ty);
-        coll |= (d < p.collision_dist) ? 1 : 0;            // game.py:185-189
+        d = distance(c.x, c.y, tx, ty);
         // kinematics.py:40-49 distance_closest_approach (arctan of a quotient, signed result)
-        T a_rel_rad = deg2rad_ref(relative_angle(o.x, o.y, tx, ty));
-        T v12x = o.v * co - tv * ct, v12y = o.v * so - tv * st;
-        T dca = d * m_sin(a_rel_rad - m_atan(v12y / v12x));
+        const T a_rel_rad = deg2rad_ref(relative_angle(c.x, c.y, tx, ty));
+        const T v12x = c.v * c.co - tv * ct, v12y = c.v * c.so - tv * st;
+        dca = d * m_sin(a_rel_rad - m_atan(v12y / v12x));
         // kinematics.py:52-79 closing_speed; v2.y uses the PLAYER's airspeed (:74), kept
-        T v2x = (tv * ct) * p.dt, v2y = (o.v * st) * p.dt;
-        T x2 = tx + v2x, y2 = ty + ((tv * st) * p.dt);
-        T ax = v1x - v2x, ay = v1y - v2y, bx = x1 - x2, by = y1 - y2;
-        T c = (m_fma(ay, by, ax * bx) / distance(x1, y1, x2, y2)) / p.dt;
-        T* q = obs_row + 5 + 3 * n;
-        q[0] = d / p.d_sep_max;
-        q[1] = dca / p.d_cpa_max;
-        q[2] = c / p.v_closing_max;
-        if (n == 0) { vc0 = c; dc0 = dca; }
+        const T v2x = (tv * ct) * p.dt, v2y = (c.v * st) * p.dt;
+        const T x2 = tx + v2x, y2 = ty + ((tv * st) * p.dt);
+        const T ax = c.v1x - v2x, ay = c.v1y - v2y, bx = c.x1 - x2, by = c.y1 - y2;
+        vc = (m_fma(ay, by, ax * bx) / distance(c.x1, c.y1, x2, y2)) / p.dt;
+    }
+}
+
+// game.py:199-203: the five player entries of the observation into the LDS row.
+template <typename T, bool FAST>
+__device__ __forceinline__ void put_own_obs(const Params<T>& p, T* row, int32_t steps, T psi, const OwnCtx<T>& c) {
+    if constexpr (FAST) {
+        row[0] = (T)steps * p.inv_max_steps;
+        row[1] = psi * Const<T>::inv360;
+        row[2] = c.d_dev * p.inv_d_dev_max;
+        row[3] = c.d_goal * p.inv_d_goal_max;
+        row[4] = c.h_goal * Const<T>::inv360;
+    } else {
+        row[0] = (T)steps / (T)p.max_steps;
+        row[1] = psi / T(360);
+        row[2] = c.d_dev / p.d_dev_max;
+        row[3] = c.d_goal / p.d_goal_max;
+        row[4] = c.h_goal / T(360);
+    }
+}
+
+// game.py:205-210: the three normalised entries of one traffic aircraft into the LDS row.
+template <typename T, bool FAST>
+__device__ __forceinline__ void put_traffic_obs(const Params<T>& p, T* q, T d, T dca, T vc) {
+    if constexpr (FAST) {
+        q[0] = d * p.inv_d_sep_max; q[1] = dca * p.inv_d_cpa_max; q[2] = vc * p.inv_v_closing_max;
+    } else {
+        q[0] = d / p.d_sep_max; q[1] = dca / p.d_cpa_max; q[2] = vc / p.v_closing_max;
+    }
+}
+
+// The C traffic aircraft of one lane (packed shapes), loaded / stored as 16-byte vectors.
+template <typename T, int C>
+struct Traffic {
+    Vec<T, C> x, y, psi, v;
+};
+template <typename T, int C>
+__device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int64_t i0) {
+    using V = Vec<T, C>;
+    Traffic<T, C> t;
+    t.x = *reinterpret_cast<const V*>(s.trf_x + i0);
+    t.y = *reinterpret_cast<const V*>(s.trf_y + i0);
+    t.psi = *reinterpret_cast<const V*>(s.trf_psi + i0);
+    t.v = *reinterpret_cast<const V*>(s.trf_v + i0);
+    return t;
+}
+
+// game.py:194-220 observe() (+ the traffic half of action() when `move`): every lane computes the
+// player-side terms (same-address inputs, identical results); lane j walks its traffic and writes
+// the observation entries into the wave's LDS tile row.  `steps` is the incremented counter.
+// Packed shapes get their traffic in registers (`tr`, loaded by the caller up front so that all
+// of a wave's loads are in flight together) and write the moved block back; the generic walk
+// loads / stores aircraft by aircraft.
+template <typename T, int C, int G, bool PACKED, bool FAST>
+__device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
+                                           int64_t e, int j, int N, int32_t steps, bool move,
+                                           Traffic<T, C>& tr, T* __restrict__ row) {
+    const OwnCtx<T> c = own_context<T, FAST>(p, o);
+    Seen<T> r;
+    r.d_goal = c.d_goal; r.h_goal = c.h_goal; r.d_dev = c.d_dev;
+    int coll = 0;
+    T vc0 = T(0), dc0 = T(0);
+    if constexpr (PACKED) {
+        using V = Vec<T, C>;
+        const int64_t i0 = e * N + (int64_t)j * C;
+        bool psi_changed = false;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            T d, dca, vc;
+            const T psi_in = tr.psi.v[k];
+            traffic_step<T, FAST>(p, c, move, tr.x.v[k], tr.y.v[k], tr.psi.v[k], tr.v.v[k], d, dca, vc);
+            psi_changed |= (tr.psi.v[k] != psi_in);
+            coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
+            put_traffic_obs<T, FAST>(p, row + 5 + 3 * (j * C + k), d, dca, vc);
+            if (k == 0) { vc0 = vc; dc0 = dca; }
+        }
+        if (move) {
+            *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
+            *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+            if (psi_changed) *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;   // injected headings >= 360 only
+        }
+    } else {
+        for (int n = j; n < N; n += G) {
+            const int64_t i = e * N + n;
+            T tx = s.trf_x[i], ty = s.trf_y[i], tpsi = s.trf_psi[i];
+            const T tv = s.trf_v[i], psi_in = tpsi;
+            T d, dca, vc;
+            traffic_step<T, FAST>(p, c, move, tx, ty, tpsi, tv, d, dca, vc);
+            if (move) {
+                s.trf_x[i] = tx;
+                s.trf_y[i] = ty;
+                if (tpsi != psi_in) s.trf_psi[i] = tpsi;
+            }
+            coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
+            put_traffic_obs<T, FAST>(p, row + 5 + 3 * n, d, dca, vc);
+            if (n == 0) { vc0 = vc; dc0 = dca; }
+        }
     }
     r.collided = group_or<G>(coll);
     r.v_closing0 = group_bcast0<G>(vc0);                  // evaluate() reads traffic[0] only,
     r.d_cpa0 = group_bcast0<G>(dc0);                      // game.py:254-255
-    if (j == 0) {                                          // game.py:199-203
-        obs_row[0] = (T)steps / (T)p.max_steps;
-        obs_row[1] = o.psi / T(360);
-        obs_row[2] = r.d_dev / p.d_dev_max;
-        obs_row[3] = r.d_goal / p.d_goal_max;
-        obs_row[4] = r.h_goal / T(360);
-    }
+    if (j == 0) put_own_obs<T, FAST>(p, row, steps, o.psi, c);
     return r;
 }
 
 // ACAS2DGame.__init__ reset distribution, game.py:80-116, from one Philox block per entity:
 // counter = (env_lo, env_hi, episode, entity) with entity 0 = player, 1 + n = traffic n;
 // words: x (bit 31 of it = starts_down for traffic 0), y, heading, airspeed factor.
-template <typename T, int G>
+template <typename T>
+__device__ __forceinline__ void reset_traffic(const ResetParams& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
+                                              uint32_t g_hi, uint32_t episode, int n, T& ox, T& oy, T& opsi,
+                                              T& ov) {
+#pragma clang fp contract(off)
+    const U4 w = philox4x32_10(U4{g_lo, g_hi, episode, 1u + (uint32_t)n}, k0, k1);
+    double x, y, psi;
+    const double v = uniform(rp.speed_factor_min, rp.speed_factor_max, u01(w.w)) * rp.airspeed;
+    if (n == 0) {
+        const double down = (double)(w.x >> 31);
+        x = rp.t0_x;
+        y = rp.t0_y_base + (down * rp.t0_y_span);
+        psi = py_mod360(rp.t0_heading_base + (down * rp.t0_heading_step) +
+                        uniform(-rp.t0_heading_jitter, rp.t0_heading_jitter, u01(w.z)));
+    } else {
+        x = uniform(0.0, rp.tn_x_max, u01(w.x));
+        y = uniform(0.0, rp.tn_y_max, u01(w.y));
+        psi = uniform(0.0, 360.0, u01(w.z));
+    }
+    ox = (T)x; oy = (T)y; opsi = (T)psi; ov = (T)v;
+}
+
+template <typename T, int C, int G, bool PACKED>
 __device__ __forceinline__ Own<T> reset_env(const ResetParams& rp, const State<T>& s, uint32_t k0,
                                             uint32_t k1, uint64_t gid, uint32_t episode, int64_t e,
-                                            int j, int N) {
+                                            int j, int N, Traffic<T, C>& tr) {
 #pragma clang fp contract(off)   // float64 here in both builds: a seed names the same episode
     const uint32_t g_lo = (uint32_t)gid, g_hi = (uint32_t)(gid >> 32);
-    U4 w = philox4x32_10(U4{g_lo, g_hi, episode, 0u}, k0, k1);
+    const U4 w = philox4x32_10(U4{g_lo, g_hi, episode, 0u}, k0, k1);
     Own<T> o;
     o.x = (T)rp.own_x0;
     o.y = (T)rp.own_y0;
@@ -288,26 +550,23 @@ __device__ __forceinline__ Own<T> reset_env(const ResetParams& rp, const State<T
     o.gx = (T)rp.goal_x;
     o.gy = (T)rp.goal_y;
     o.a_lat = T(0);
-    for (int n = j; n < N; n += G) {
-        w = philox4x32_10(U4{g_lo, g_hi, episode, 1u + (uint32_t)n}, k0, k1);
-        double x, y, psi;
-        double v = uniform(rp.speed_factor_min, rp.speed_factor_max, u01(w.w)) * rp.airspeed;
-        if (n == 0) {
-            double down = (double)(w.x >> 31);
-            x = rp.t0_x;
-            y = rp.t0_y_base + (down * rp.t0_y_span);
-            psi = py_mod360(rp.t0_heading_base + (down * rp.t0_heading_step) +
-                            uniform(-rp.t0_heading_jitter, rp.t0_heading_jitter, u01(w.z)));
-        } else {
-            x = uniform(0.0, rp.tn_x_max, u01(w.x));
-            y = uniform(0.0, rp.tn_y_max, u01(w.y));
-            psi = uniform(0.0, 360.0, u01(w.z));
+    if constexpr (PACKED) {
+        using V = Vec<T, C>;
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+            reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, j * C + k, tr.x.v[k], tr.y.v[k], tr.psi.v[k], tr.v.v[k]);
+        const int64_t i0 = e * N + (int64_t)j * C;
+        *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
+        *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+        *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;
+        *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
+    } else {
+        for (int n = j; n < N; n += G) {
+            const int64_t i = e * N + n;
+            T x, y, psi, v;
+            reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, psi, v);
+            s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = psi; s.trf_v[i] = v;
         }
-        const int64_t i = e * N + n;
-        s.trf_x[i] = (T)x;
-        s.trf_y[i] = (T)y;
-        s.trf_psi[i] = (T)psi;
-        s.trf_v[i] = (T)v;
     }
     if (j == 0) {
         s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi; s.own_v[e] = o.v;
@@ -316,106 +575,271 @@ __device__ __forceinline__ Own<T> reset_env(const ResetParams& rp, const State<T
     return o;
 }
 
-// ---- kernels ------------------------------------------------------------------------------------------
+// Entity `ent` of a fresh episode from ONE Philox block: ent 0 = the player (only its heading is
+// random, returned in opsi; game.py:85-92), ent n + 1 = traffic n (game.py:96-116).  Bitwise the
+// same draws as reset_own_psi() / reset_traffic().
+template <typename T>
+__device__ __forceinline__ void reset_entity(const ResetParams& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
+                                             uint32_t g_hi, uint32_t episode, int ent, T& ox, T& oy, T& opsi,
+                                             T& ov) {
+#pragma clang fp contract(off)
+    const U4 w = philox4x32_10(U4{g_lo, g_hi, episode, (uint32_t)ent}, k0, k1);
+    const double u_psi = u01(w.z);
+    const bool own = ent == 0, first = ent == 1;
+    const double down = (double)(w.x >> 31);
+    // heading: base + jitter * (2u - 1) for the player / traffic 0, 360 u for the rest
+    const double jitter = own ? rp.own_heading_jitter : rp.t0_heading_jitter;
+    const double base = own ? rp.own_heading0 : (rp.t0_heading_base + (down * rp.t0_heading_step));
+    const double psi_special = py_mod360(base + uniform(-jitter, jitter, u_psi));
+    const double psi = (own || first) ? psi_special : uniform(0.0, 360.0, u_psi);
+    const double x = first ? rp.t0_x : uniform(0.0, rp.tn_x_max, u01(w.x));
+    const double y = first ? (rp.t0_y_base + (down * rp.t0_y_span)) : uniform(0.0, rp.tn_y_max, u01(w.y));
+    const double v = uniform(rp.speed_factor_min, rp.speed_factor_max, u01(w.w)) * rp.airspeed;
+    ox = (T)x; oy = (T)y; opsi = (T)psi; ov = (T)v;
+}
 
-// ACAS2DEnv.step(), environment.py:29-42.
-template <typename T, int G, bool AUTO_RESET>
-__global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p, ResetParams rp, State<T> s,
-                                                      StepIO<T> io, uint32_t k0, uint32_t k1,
-                                                      int64_t env_offset, int64_t n_envs, int N) {
-    const int64_t tid = remap_block() * kBlock + threadIdx.x;
-    const int64_t e = tid / G;
-    const int j = (int)(tid % G);
-    if (e >= n_envs) return;                      // whole groups leave together (G divides 256)
+// Player draw of a fresh episode (entity 0 of the env's Philox stream), game.py:85-92.
+template <typename T>
+__device__ __forceinline__ T reset_own_psi(const ResetParams& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
+                                           uint32_t g_hi, uint32_t episode) {
+#pragma clang fp contract(off)
+    const U4 w = philox4x32_10(U4{g_lo, g_hi, episode, 0u}, k0, k1);
+    return (T)py_mod360(rp.own_heading0 + uniform(-rp.own_heading_jitter, rp.own_heading_jitter, u01(w.z)));
+}
+
+// Wave-cooperative reset of ONE finished env inside the step kernel (SB3 DummyVecEnv.step_wait
+// semantics).  The owner group alone would run 1 + C Philox blocks and a whole observe()
+// back to back while the rest of the chip waits for this wave (the kernel ends with its slowest
+// wave); instead all 64 lanes of the wave take one ENTITY each -- lane 0 the player, lane n the
+// traffic aircraft n-1 (strided by 64 beyond that) -- so the new episode costs one Philox block
+// and one traffic_step() of latency.  Must be called by the whole wave (wave-uniform arguments).
+template <typename T, bool FAST>
+__device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetParams& rp, const State<T>& s,
+                                               const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
+                                               int64_t e, int N, int lane, T total, int32_t steps,
+                                               uint32_t episode_prev, T* __restrict__ row) {
     const int D = 5 + 3 * N;
-    T* obs_row = io.obs + e * D;
-
-    Own<T> o{s.own_x[e], s.own_y[e], s.own_psi[e], s.own_v[e], T(0), s.goal_x[e], s.goal_y[e]};
-    int32_t steps = s.steps[e];
-    bool frozen = false;
-    if constexpr (!AUTO_RESET) frozen = s.status[e] != 0;   // game.py:243-245
-
-    // game.py:225 + aircraft.py:16-26 for the player
-    o.a_lat = io.actions[e] * p.acc_lat_limit;
-    {
-        T psi_dot = o.a_lat / (o.v * p.dt);
-        o.psi = py_mod360(o.psi + (psi_dot * p.dt));
-        T sn, cs;
-        m_sincos(deg2rad_ref(o.psi), &sn, &cs);
-        o.x = o.x + ((o.v * cs) * p.dt);
-        o.y = o.y + ((o.v * sn) * p.dt);
-    }
-    steps += 1;                                                       // game.py:197
-    Seen<T> r = observe<T, G>(p, s, o, e, j, N, steps, !frozen, obs_row);
-
-    // game.py:249-292 evaluate()
-    T rw = step_reward_5(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
-    rw = rw * (T(1) - ((T)steps / (T)p.max_steps));                  // :262-263
-    const bool at_goal = r.d_goal < p.goal_radius;                    // :191-192
-    if (r.collided) rw += p.reward_collision;                         // :279-280
-    if (at_goal) rw += p.reward_goal;                                 // :283-284
-    // game.py:294-314 is_done(): timeout > collision > goal
-    const uint8_t oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
-    T total = T(0);
-    if (j == 0) {
-        total = s.total_reward[e] + rw;                               // :287
-        io.reward[e] = rw;
-        io.done[e] = oc != 0;
-        io.outcome[e] = oc;
-    }
-    if (oc == 0 || !AUTO_RESET) {
-        if (j == 0) {
-            s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi;
-            s.steps[e] = steps;
-            s.total_reward[e] = total;
-            if constexpr (!AUTO_RESET) { if (oc) s.status[e] = oc; }
-        }
-        return;
-    }
-
-    // ---- SB3 DummyVecEnv.step_wait semantics for a finished env (group-uniform branch) ----
-    if (io.term_obs) {                        // every lane copies exactly the entries it wrote
+    if (io.term_obs) {                                   // the finished episode's last observation
         T* t_row = io.term_obs + e * D;
-        for (int n = j; n < N; n += G)
-            for (int k = 0; k < 3; ++k) t_row[5 + 3 * n + k] = obs_row[5 + 3 * n + k];
-        if (j == 0)
-            for (int k = 0; k < 5; ++k) t_row[k] = obs_row[k];
+        for (int i = lane; i < D; i += 64) t_row[i] = row[i];
     }
-    const uint32_t episode = s.episode[e] + 1u;
-    if (j == 0) {
+    const uint32_t episode = episode_prev + 1u;
+    wave_lds_fence();                                    // row reads precede its rewrite below
+    const uint64_t gid = (uint64_t)(env_offset + e);
+    const uint32_t g_lo = (uint32_t)gid, g_hi = (uint32_t)(gid >> 32);
+
+    // entity `lane`: the player (lane 0) or traffic lane-1; further traffic in strides of 64.
+    // ONE Philox block per lane (a divergent player / traffic split would run two back to back).
+    T tx = T(0), ty = T(0), tpsi = T(0), tv = T(0), psi_own = T(0);
+    if (lane <= N) {
+        reset_entity<T>(rp, k0, k1, g_lo, g_hi, episode, lane, tx, ty, tpsi, tv);
+        if (lane == 0) {
+            psi_own = tpsi;
+        } else {
+            const int64_t i = e * N + (lane - 1);
+            s.trf_x[i] = tx; s.trf_y[i] = ty; s.trf_psi[i] = tpsi; s.trf_v[i] = tv;
+        }
+    }
+    for (int n = lane + 63; n < N; n += 64) {            // N > 63 only
+        T x, y, ps, v;
+        reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, ps, v);
+        const int64_t i = e * N + n;
+        s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = ps; s.trf_v[i] = v;
+    }
+    psi_own = __shfl(psi_own, 0, 64);
+    const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+    const OwnCtx<T> c = own_context<T, FAST>(p, o);
+
+    // environment.py:44-48: the new episode's first observation (steps becomes 1)
+    if (lane >= 1 && lane <= N) {
+        T d, dca, vc;
+        traffic_step<T, FAST>(p, c, false, tx, ty, tpsi, tv, d, dca, vc);
+        put_traffic_obs<T, FAST>(p, row + 5 + 3 * (lane - 1), d, dca, vc);
+    }
+    for (int n = lane + 63; n < N; n += 64) {
+        const int64_t i = e * N + n;
+        T x = s.trf_x[i], y = s.trf_y[i], ps = s.trf_psi[i];   // written by this lane above
+        T d, dca, vc;
+        traffic_step<T, FAST>(p, c, false, x, y, ps, s.trf_v[i], d, dca, vc);
+        put_traffic_obs<T, FAST>(p, row + 5 + 3 * n, d, dca, vc);
+    }
+    if (lane == 0) {
         if (io.ep_return) io.ep_return[e] = total;
         if (io.ep_steps) io.ep_steps[e] = steps;
         s.episode[e] = episode;
-        s.steps[e] = 1;                                               // environment.py:47
+        s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi; s.own_v[e] = o.v;
+        s.goal_x[e] = o.gx; s.goal_y[e] = o.gy;
+        s.steps[e] = 1;                                                   // environment.py:47
         s.total_reward[e] = T(0);
+        put_own_obs<T, FAST>(p, row, 1, o.psi, c);
     }
-    Own<T> fresh = reset_env<T, G>(rp, s, k0, k1, (uint64_t)(env_offset + e), episode, e, j, N);
-    observe<T, G>(p, s, fresh, e, j, N, 1, false, obs_row);
+}
+
+// Flush the wave's LDS tile (`count` values, the contiguous slice dst[0 .. count) of obs[E][D])
+// with lane-linear stores: 16 bytes per lane where the slice is 16-byte aligned, else one value.
+template <typename T>
+__device__ __forceinline__ void flush_tile(const T* __restrict__ tile, T* __restrict__ dst, int count,
+                                           int lane) {
+    constexpr int W = 16 / sizeof(T);
+    using V = Vec<T, W>;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        const int nv = count / W;
+        for (int i = lane; i < nv; i += 64)
+            reinterpret_cast<V*>(dst)[i] = reinterpret_cast<const V*>(tile)[i];
+        for (int i = nv * W + lane; i < count; i += 64) dst[i] = tile[i];
+    } else {
+        for (int i = lane; i < count; i += 64) dst[i] = tile[i];
+    }
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------
+// Dynamic LDS: kWavesPerBlock tiles of (64 / G) * D values, 16-byte aligned.
+template <typename T>
+__device__ __forceinline__ T* wave_tile(int tile_elems) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    return reinterpret_cast<T*>(lds_raw) + (threadIdx.x >> 6) * tile_elems;
+}
+
+// ACAS2DEnv.step(), environment.py:29-42.
+template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST>
+__global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetParams rp, State<T> s,
+                                                      StepIO<T> io, uint32_t k0, uint32_t k1,
+                                                      int64_t env_offset, int64_t n_envs, int N,
+                                                      int tile_elems) {
+    const Params<T> p = pinned(p_arg);
+    constexpr int EPW = 64 / G;                    // envs per wavefront
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
+    const int64_t wave = remap_block() * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t e_wave = wave * EPW;             // first env of this wave
+    if (e_wave >= n_envs) return;                  // whole wave idle
+    const int64_t e = e_wave + el;
+    const bool active = e < n_envs;                // whole groups are active or not
+    const int D = 5 + 3 * N;
+    T* tile = wave_tile<T>(tile_elems);
+    T* row = tile + el * D;
+    const int n_rows = (int)((n_envs - e_wave) < EPW ? (n_envs - e_wave) : EPW);
+
+    ACAS2D_STAMP(0, wave, lane, false);
+    ACAS2D_STAMP(1, wave, lane, false);
+    uint8_t oc = 0;
+    int32_t steps = 0;
+    uint32_t episode = 0;
+    T total = T(0);
+    Own<T> o{};
+    if (active) {
+        // ---- every load of this lane up front: one memory round trip, all requests in flight ----
+        Traffic<T, C> tr;
+        if constexpr (PACKED) tr = load_traffic<T, C>(s, e * N + (int64_t)j * C);
+        o = Own<T>{s.own_x[e], s.own_y[e], s.own_psi[e], s.own_v[e], T(0), s.goal_x[e], s.goal_y[e]};
+        const T action = io.actions[e];
+        steps = s.steps[e];
+        total = s.total_reward[e];
+        bool frozen = false;
+        if constexpr (AUTO_RESET) episode = s.episode[e];
+        else frozen = s.status[e] != 0;                                   // game.py:243-245
+        ACAS2D_STAMP(2, wave, lane, true);
+
+        // game.py:225 + aircraft.py:16-26 for the player
+        o.a_lat = action * p.acc_lat_limit;
+        if constexpr (FAST) {
+            o.psi = py_mod360(o.psi + o.a_lat * f_rcp(o.v));   // (a_lat / (v dt)) dt
+            T sn, cs;
+            f_sincos_rev(o.psi * Const<T>::inv360, &sn, &cs);
+            const T vdt = o.v * p.dt;
+            o.x = m_fma(vdt, cs, o.x);
+            o.y = m_fma(vdt, sn, o.y);
+        } else {
+            T psi_dot = o.a_lat / (o.v * p.dt);
+            o.psi = py_mod360(o.psi + (psi_dot * p.dt));
+            T sn, cs;
+            m_sincos(deg2rad_ref(o.psi), &sn, &cs);
+            o.x = o.x + ((o.v * cs) * p.dt);
+            o.y = o.y + ((o.v * sn) * p.dt);
+        }
+        steps += 1;                                                       // game.py:197
+        Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, e, j, N, steps, !frozen, tr, row);
+
+        // game.py:249-292 evaluate()
+        T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
+        if constexpr (FAST) rw = rw * (T(1) - (T)steps * p.inv_max_steps);
+        else rw = rw * (T(1) - ((T)steps / (T)p.max_steps));              // :262-263
+        const bool at_goal = r.d_goal < p.goal_radius;                    // :191-192
+        if (r.collided) rw += p.reward_collision;                         // :279-280
+        if (at_goal) rw += p.reward_goal;                                 // :283-284
+        // game.py:294-314 is_done(): timeout > collision > goal
+        oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
+        if (j == 0) {
+            total = total + rw;                                           // :287
+            io.reward[e] = rw;
+            io.done[e] = oc != 0;
+            io.outcome[e] = oc;
+            if (oc == 0 || !AUTO_RESET) {
+                s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi;
+                s.steps[e] = steps;
+                s.total_reward[e] = total;
+                if constexpr (!AUTO_RESET) { if (oc) s.status[e] = oc; }
+            }
+        }
+    }
+
+    ACAS2D_STAMP(3, wave, lane, false);
+    if constexpr (AUTO_RESET) {
+        // ---- finished envs: one bit per env (its group's lane 0), handled by the whole wave ----
+        unsigned long long dm = __ballot(oc != 0 && j == 0);
+        if (dm) {
+            wave_lds_fence();                         // every row of the tile is complete
+            while (dm) {
+                const int src = __ffsll((long long)dm) - 1;           // wave-uniform
+                dm &= dm - 1;
+                const int el_d = src / G;
+                wave_reset_env<T, FAST>(p, rp, s, io, k0, k1, env_offset, e_wave + el_d, N, lane,
+                                        __shfl(total, src, 64), __shfl(steps, src, 64),
+                                        (uint32_t)__shfl((int)episode, src, 64), tile + el_d * D);
+            }
+        }
+    }
+    ACAS2D_STAMP(4, wave, lane, false);
+    wave_lds_fence();
+    flush_tile<T>(tile, io.obs + e_wave * D, n_rows * D, lane);
+    ACAS2D_STAMP(5, wave, lane, false);
+    ACAS2D_STAMP(6, wave, lane, true);
+    ACAS2D_STAMP(7, wave, lane, false);
 }
 
 // ACAS2DEnv.reset(), environment.py:44-48.
-template <typename T, int G>
+template <typename T, int C, int G, bool PACKED, bool FAST>
 __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams rp, State<T> s,
                                                        const uint8_t* __restrict__ mask, T* obs,
                                                        int do_init, uint32_t k0, uint32_t k1,
-                                                       int64_t env_offset, int64_t n_envs, int N) {
-    const int64_t tid = remap_block() * kBlock + threadIdx.x;
-    const int64_t e = tid / G;
-    const int j = (int)(tid % G);
+                                                       int64_t env_offset, int64_t n_envs, int N,
+                                                       int tile_elems) {
+    constexpr int EPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (G - 1), el = lane / G;
+    const int64_t wave = remap_block() * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t e = wave * EPW + el;
     if (e >= n_envs) return;
     if (mask && !mask[e]) return;
+    const int D = 5 + 3 * N;
+    T* row = wave_tile<T>(tile_elems) + el * D;
     Own<T> o;
+    Traffic<T, C> tr;
     int32_t steps;
     if (do_init) {
-        o = reset_env<T, G>(rp, s, k0, k1, (uint64_t)(env_offset + e), s.episode[e], e, j, N);
+        o = reset_env<T, C, G, PACKED>(rp, s, k0, k1, (uint64_t)(env_offset + e), s.episode[e], e, j, N, tr);
         steps = 0;
     } else {
+        if constexpr (PACKED) tr = load_traffic<T, C>(s, e * N + (int64_t)j * C);
         o = Own<T>{s.own_x[e], s.own_y[e], s.own_psi[e], s.own_v[e], T(0), s.goal_x[e], s.goal_y[e]};
         steps = s.steps[e];
     }
     if (obs) {
         steps += 1;
-        observe<T, G>(p, s, o, e, j, N, steps, false, obs + e * (5 + 3 * N));
+        observe<T, C, G, PACKED, FAST>(p, s, o, e, j, N, steps, false, tr, row);
+        wave_lds_fence();
+        T* dst = obs + e * D;                         // masked rows are not contiguous: per-row copy
+        for (int i = j; i < D; i += G) dst[i] = row[i];
     }
     if (j == 0) {
         s.steps[e] = steps;
@@ -425,7 +849,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams 
 }
 
 // ---- host-side launchers (instantiated per element type in acas2d_f32.hip / acas2d_f64.hip) ----
-int lanes_per_env(int n_traffic);
+struct Shape { int C, G; bool packed; };
+Shape choose_shape(int n_traffic, int elem_size);
 
 template <typename T>
 int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, uint32_t flags,

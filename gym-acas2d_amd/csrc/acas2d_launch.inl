@@ -1,7 +1,10 @@
 // acas2d_launch.inl -- host-side launchers, included by acas2d_f32.hip and acas2d_f64.hip which
-// then instantiate launch_step<T> / launch_reset<T> for their element type.  (Two translation
-// units so that the float64 parity build can be compiled with -ffp-contract=off while the
-// float32 throughput build keeps fused multiply-adds.)
+// define ACAS2D_PACKED_SHAPES(X) (the (C, G) pairs to instantiate for their element type) and
+// kFast, then instantiate launch_step<T> / launch_reset<T>.  (Two translation units so that the
+// float64 parity build can be compiled with -ffp-contract=off while the float32 throughput build
+// keeps fused multiply-adds.)
+#include <stdlib.h>
+
 #include "acas2d_kernels.hpp"
 
 namespace acas2d {
@@ -15,6 +18,11 @@ static Params<T> make_params(const Acas2dConfig& c) {
     p.d_cpa_max = (T)c.d_cpa_max; p.v_closing_max = (T)c.v_closing_max;
     p.rw_d_goal_max = (T)c.rw_d_goal_max; p.rw_d_dev_max = (T)c.rw_d_dev_max;
     p.reward_goal = (T)c.reward_goal; p.reward_collision = (T)c.reward_collision;
+    p.inv_dt = (T)(1.0 / c.dt); p.inv_d_goal_max = (T)(1.0 / c.d_goal_max);
+    p.inv_d_dev_max = (T)(1.0 / c.d_dev_max); p.inv_d_sep_max = (T)(1.0 / c.d_sep_max);
+    p.inv_d_cpa_max = (T)(1.0 / c.d_cpa_max); p.inv_v_closing_max = (T)(1.0 / c.v_closing_max);
+    p.inv_rw_d_goal_max = (T)(1.0 / c.rw_d_goal_max); p.inv_rw_d_dev_max = (T)(1.0 / c.rw_d_dev_max);
+    p.inv_safe_distance = (T)(1.0 / c.safe_distance); p.inv_max_steps = (T)(1.0 / (double)c.max_steps);
     p.max_steps = c.max_steps;
     return p;
 }
@@ -38,27 +46,77 @@ static bool state_complete(const Acas2dState* s) {
            s->trf_y && s->trf_psi && s->trf_v && s->steps && s->total_reward && s->status && s->episode;
 }
 
-static int grid_for(int64_t n_envs, int G, unsigned* grid) {
-    const int64_t blocks = (n_envs * G + kBlock - 1) / kBlock;
-    if (blocks > 0x7fffffffLL) { set_error("n_envs * lanes_per_env = %lld * %d exceeds the grid limit", (long long)n_envs, G); return ACAS2D_EINVAL; }
-    *grid = (unsigned)blocks;
-    return ACAS2D_OK;
-}
-
 static int check_launch(const char* what) {
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(err)); return ACAS2D_EHIP; }
     return ACAS2D_OK;
 }
 
-template <typename T, int G>
-static void step_g(bool auto_reset, unsigned grid, hipStream_t stream, const Params<T>& p,
-                   const ResetParams& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
-                   int64_t env_offset, int64_t n_envs, int N) {
+// Launch geometry for a shape: one env per G lanes, 64 / G envs per wavefront, 4 wavefronts per
+// workgroup, one LDS observation tile per wavefront.
+struct Geometry { unsigned grid; int tile_elems; size_t lds_bytes; };
+
+template <typename T>
+static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g) {
+    const int64_t epw = 64 / sh.G, envs_per_block = epw * kWavesPerBlock;
+    const int64_t blocks = (n_envs + envs_per_block - 1) / envs_per_block;
+    if (blocks > 0x7fffffffLL) { set_error("n_envs = %lld exceeds the grid limit", (long long)n_envs); return ACAS2D_EINVAL; }
+    const int W = 16 / (int)sizeof(T);
+    const int64_t elems = ((epw * (5 + 3 * (int64_t)n_traffic) + W - 1) / W) * W;
+    const int64_t bytes = elems * kWavesPerBlock * (int64_t)sizeof(T);
+    if (bytes > 64 * 1024) {
+        set_error("n_traffic = %d needs a %lld-byte LDS observation tile per workgroup (limit 65536)", n_traffic, (long long)bytes);
+        return ACAS2D_EINVAL;
+    }
+    g->grid = (unsigned)blocks; g->tile_elems = (int)elems; g->lds_bytes = (size_t)bytes;
+    return ACAS2D_OK;
+}
+
+template <typename T, int C, int G, bool PACKED>
+static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, const Params<T>& p,
+                       const ResetParams& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
+                       int64_t env_offset, int64_t n_envs, int N) {
     if (auto_reset)
-        hipLaunchKernelGGL((step_kernel<T, G, true>), dim3(grid), dim3(kBlock), 0, stream, p, rp, s, io, k0, k1, env_offset, n_envs, N);
+        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems);
     else
-        hipLaunchKernelGGL((step_kernel<T, G, false>), dim3(grid), dim3(kBlock), 0, stream, p, rp, s, io, k0, k1, env_offset, n_envs, N);
+        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, kFast>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems);
+}
+
+template <typename T, int C, int G, bool PACKED>
+static void reset_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
+                        const State<T>& s, const uint8_t* mask, T* obs, int do_init, uint32_t k0, uint32_t k1,
+                        int64_t env_offset, int64_t n_envs, int N) {
+    hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, kFast>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+                       p, rp, s, mask, obs, do_init, k0, k1, env_offset, n_envs, N, g.tile_elems);
+}
+
+static bool shape_instantiated(const Shape& sh) {
+    if (!sh.packed) return sh.C == 1 && (sh.G == 1 || sh.G == 4 || sh.G == 16 || sh.G == 64);
+#define X(C_, G_) if (sh.C == C_ && sh.G == G_) return true;
+    ACAS2D_PACKED_SHAPES(X)
+#undef X
+    return false;
+}
+
+// Shape for (n_traffic, element type): the tuned default of choose_shape(), or the override
+// ACAS2D_SHAPE="C,G" (packed, needs C*G == n_traffic) / "generic,G" from the environment.
+template <typename T>
+static int resolve_shape(int n_traffic, Shape* out) {
+    Shape sh = choose_shape(n_traffic, (int)sizeof(T));
+    if (const char* ov = getenv("ACAS2D_SHAPE")) {
+        int a = 0, b = 0;
+        if (sscanf(ov, "generic,%d", &b) == 1) sh = Shape{1, b, false};
+        else if (sscanf(ov, "%d,%d", &a, &b) == 2) sh = Shape{a, b, true};
+        if (sh.packed && sh.C * sh.G != n_traffic) { set_error("ACAS2D_SHAPE=%s does not tile n_traffic=%d", ov, n_traffic); return ACAS2D_EINVAL; }
+    }
+    if (!shape_instantiated(sh)) {
+        if (sh.packed) sh = Shape{1, n_traffic >= 64 ? 64 : (n_traffic >= 16 ? 16 : (n_traffic >= 4 ? 4 : 1)), false};
+        if (!shape_instantiated(sh)) { set_error("no kernel for shape C=%d G=%d", sh.C, sh.G); return ACAS2D_EINVAL; }
+    }
+    *out = sh;
+    return ACAS2D_OK;
 }
 
 template <typename T>
@@ -71,9 +129,10 @@ int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStep
     if (n_traffic < 1) { set_error("acas2d_step: n_traffic = %d (the reference needs traffic[0], game.py:254)", n_traffic); return ACAS2D_EINVAL; }
     if (n_envs < 0 || env_offset < 0) { set_error("acas2d_step: negative n_envs / env_offset"); return ACAS2D_EINVAL; }
     if (n_envs == 0) return ACAS2D_OK;
-    const int G = lanes_per_env(n_traffic);
-    unsigned grid;
-    if (int rc = grid_for(n_envs, G, &grid)) return rc;
+    Shape sh;
+    if (int rc = resolve_shape<T>(n_traffic, &sh)) return rc;
+    Geometry g;
+    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
     const ResetParams rp = make_reset_params(*cfg);
     const State<T> s = make_state<T>(*st);
@@ -81,23 +140,19 @@ int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStep
                        (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const bool ar = (flags & ACAS2D_AUTO_RESET) != 0;
-    switch (G) {
-        case 1:  step_g<T, 1>(ar, grid, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 2:  step_g<T, 2>(ar, grid, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 4:  step_g<T, 4>(ar, grid, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 8:  step_g<T, 8>(ar, grid, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 16: step_g<T, 16>(ar, grid, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 32: step_g<T, 32>(ar, grid, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
-        default: step_g<T, 64>(ar, grid, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+    if (sh.packed) {
+#define X(C_, G_) if (sh.C == C_ && sh.G == G_) step_shape<T, C_, G_, true>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic);
+        ACAS2D_PACKED_SHAPES(X)
+#undef X
+    } else {
+        switch (sh.G) {
+            case 1:  step_shape<T, 1, 1, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 4:  step_shape<T, 1, 4, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 16: step_shape<T, 1, 16, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            default: step_shape<T, 1, 64, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+        }
     }
     return check_launch("acas2d_step launch");
-}
-
-template <typename T, int G>
-static void reset_g(unsigned grid, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
-                    const State<T>& s, const uint8_t* mask, T* obs, int do_init, uint32_t k0, uint32_t k1,
-                    int64_t env_offset, int64_t n_envs, int N) {
-    hipLaunchKernelGGL((reset_kernel<T, G>), dim3(grid), dim3(kBlock), 0, stream, p, rp, s, mask, obs, do_init, k0, k1, env_offset, n_envs, N);
 }
 
 template <typename T>
@@ -109,23 +164,37 @@ int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* 
     if (n_traffic < 1) { set_error("acas2d_reset: n_traffic = %d", n_traffic); return ACAS2D_EINVAL; }
     if (n_envs < 0 || env_offset < 0) { set_error("acas2d_reset: negative n_envs / env_offset"); return ACAS2D_EINVAL; }
     if (n_envs == 0) return ACAS2D_OK;
-    const int G = lanes_per_env(n_traffic);
-    unsigned grid;
-    if (int rc = grid_for(n_envs, G, &grid)) return rc;
+    Shape sh;
+    if (int rc = resolve_shape<T>(n_traffic, &sh)) return rc;
+    Geometry g;
+    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
     const ResetParams rp = make_reset_params(*cfg);
     const State<T> s = make_state<T>(*st);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    switch (G) {
-        case 1:  reset_g<T, 1>(grid, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 2:  reset_g<T, 2>(grid, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 4:  reset_g<T, 4>(grid, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 8:  reset_g<T, 8>(grid, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 16: reset_g<T, 16>(grid, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
-        case 32: reset_g<T, 32>(grid, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
-        default: reset_g<T, 64>(grid, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+    if (sh.packed) {
+#define X(C_, G_) if (sh.C == C_ && sh.G == G_) reset_shape<T, C_, G_, true>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic);
+        ACAS2D_PACKED_SHAPES(X)
+#undef X
+    } else {
+        switch (sh.G) {
+            case 1:  reset_shape<T, 1, 1, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 4:  reset_shape<T, 1, 4, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 16: reset_shape<T, 1, 16, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            default: reset_shape<T, 1, 64, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+        }
     }
     return check_launch("acas2d_reset launch");
+}
+
+template <typename T>
+int shape_geometry(int64_t n_envs, int32_t n_traffic, int32_t* lanes, int32_t* per_lane, int64_t* grid) {
+    Shape sh;
+    if (int rc = resolve_shape<T>(n_traffic, &sh)) return rc;
+    Geometry g;
+    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
+    *lanes = sh.G; *per_lane = sh.packed ? sh.C : -1; *grid = g.grid;
+    return ACAS2D_OK;
 }
 
 }  // namespace acas2d

@@ -77,8 +77,8 @@ def lib():
         f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.c_void_p, C.c_void_p, C.c_int32,
                       C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
     L.acas2d_launch_geometry.restype = C.c_int
-    L.acas2d_launch_geometry.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_int32),
-                                         C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    L.acas2d_launch_geometry.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     if L.acas2d_abi_version() != ABI_VERSION:
         raise NativeLibraryError("ABI version %d != %d" % (L.acas2d_abi_version(), ABI_VERSION))
     if L.acas2d_config_size() != C.sizeof(CConfig):
@@ -93,7 +93,9 @@ def check(rc):
         raise RuntimeError("acas2d: error %d: %s" % (rc, lib().acas2d_last_error().decode()))
 
 
-def launch_geometry(n_envs, n_traffic):
-    g, b, n = C.c_int32(), C.c_int32(), C.c_int64()
-    check(lib().acas2d_launch_geometry(n_envs, n_traffic, C.byref(g), C.byref(b), C.byref(n)))
-    return {"lanes_per_env": g.value, "block_threads": b.value, "grid_blocks": n.value}
+def launch_geometry(n_envs, n_traffic, elem_size=4):
+    g, c, b, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    check(lib().acas2d_launch_geometry(n_envs, n_traffic, elem_size, C.byref(g), C.byref(c), C.byref(b),
+                                       C.byref(n)))
+    return {"lanes_per_env": g.value, "traffic_per_lane": c.value, "block_threads": b.value,
+            "grid_blocks": n.value}

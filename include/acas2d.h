@@ -150,10 +150,12 @@ int acas2d_reset_f64(const Acas2dConfig *cfg, const Acas2dState *state, const ui
                      int64_t n_envs, int32_t n_traffic, void *stream);
 
 /*
- * Launch geometry chosen for (n_envs, n_traffic): lanes per env (power of two <= 64), threads
- * per workgroup and number of workgroups.  Informational (bench / DESIGN.md); returns 0.
+ * Launch geometry chosen for (n_envs, n_traffic, elem_size = 4 | 8): lanes per env (power of two
+ * <= 64), traffic aircraft per lane (-1: generic strided walk), threads per workgroup and number
+ * of workgroups.  Informational (bench / DESIGN.md); output pointers may be NULL.
  */
-int acas2d_launch_geometry(int64_t n_envs, int32_t n_traffic, int32_t *lanes_per_env,
+int acas2d_launch_geometry(int64_t n_envs, int32_t n_traffic, int32_t elem_size,
+                           int32_t *lanes_per_env, int32_t *traffic_per_lane,
                            int32_t *block_threads, int64_t *grid_blocks);
 
 #ifdef __cplusplus

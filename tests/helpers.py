@@ -22,7 +22,8 @@ def parity_reset_states(cfg, seed, skip, count):
     """Episodes number skip .. skip+count-1 of the reference's MT19937 stream after seed."""
     import gym_acas2d_amd as g
     rng = random.Random(seed)
-    g.reset_parity.draw_episodes(cfg, skip, rng)
+    if skip:
+        g.reset_parity.draw_episodes(cfg, skip, rng)
     return g.reset_parity.draw_episodes(cfg, count, rng)
 
 

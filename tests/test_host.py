@@ -98,12 +98,18 @@ def test_c_abi_argument_validation_needs_no_gpu(g):
     assert L.acas2d_reset_f32(C.byref(cfg), C.byref(st), None, None, 1, 0, 0, 4, 1, None) == -22
     assert L.acas2d_reset_f32(C.byref(cfg), C.byref(full), None, None, 1, 0, 0, 0, 1, None) == 0
     with pytest.raises(RuntimeError, match="acas2d: error -22"):
-        g.native.check(L.acas2d_launch_geometry(-1, 1, None, None, None))
-    assert g.native.launch_geometry(65536, 8) == {"lanes_per_env": 8, "block_threads": 256, "grid_blocks": 2048}
-    assert g.native.launch_geometry(4096, 3)["lanes_per_env"] == 4
+        g.native.check(L.acas2d_launch_geometry(-1, 1, 4, None, None, None, None))
+    # headline config: 4 traffic per lane as one 16-byte vector, 2 lanes per env, 32 envs per wave
+    assert g.native.launch_geometry(65536, 8) == {"lanes_per_env": 2, "traffic_per_lane": 4,
+                                                  "block_threads": 256, "grid_blocks": 512}
+    assert g.native.launch_geometry(65536, 8, 8)["traffic_per_lane"] == 2         # float64: 2 per 16 B
+    assert g.native.launch_geometry(4096, 3)["lanes_per_env"] == 1
     assert g.native.launch_geometry(10, 1)["lanes_per_env"] == 1
-    assert g.native.launch_geometry(65536, 64) == {"lanes_per_env": 64, "block_threads": 256, "grid_blocks": 16384}
-    assert g.native.launch_geometry(7, 200)["lanes_per_env"] == 64
+    assert g.native.launch_geometry(65536, 64)["lanes_per_env"] == 16
+    geo = g.native.launch_geometry(7, 200)                                          # generic walk
+    assert geo["lanes_per_env"] == 64 and geo["traffic_per_lane"] == -1
+    with pytest.raises(RuntimeError, match="LDS"):
+        g.native.launch_geometry(16, 5000)
 
 
 def test_no_cpu_fallback(g, monkeypatch):
