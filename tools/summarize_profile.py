@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_round.sh output directory: kernel-trace statistics of the step
+kernel and HBM traffic per launch from the FETCH_SIZE / WRITE_SIZE passes.
+
+gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE / WRITE_SIZE are in KiB-units of
+the L2's memory-side requests (x1024 -> bytes); FETCH_SIZE reads exactly 1/2 of the bytes of a
+wide (16 B/lane) coalesced streaming read and is uncalibrated for other widths, WRITE_SIZE is
+exact for 16 B/lane streaming stores.  This kernel mixes 16-byte traffic-block accesses with
+4-byte per-env scalars, so the read side is CALIBRATED on a known byte count in the same access
+pattern: at 4 194 304 envs (working set 1.5 GB >> 256 MB Infinity Cache) every input byte is
+fetched from HBM exactly once, so  k_read = algorithmic_read_bytes / (FETCH_SIZE * 1024)  there,
+and the same factor prices the headline size."""
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+d = sys.argv[1]
+N, S = 8, 4
+
+
+def counter(name, E):
+    vals = []
+    for f in glob.glob(os.path.join(d, "pmc_%s_%d" % (name, E), "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "step_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                vals.append(float(r["Counter_Value"]))
+    vals = vals[len(vals) // 4:]
+    return statistics.mean(vals) if vals else None
+
+
+def alg_bytes(E):
+    rd = E * (S * (4 + 2 + 4 * N + 1) + 4)            # own x,y,psi,v + goal + traffic + action + steps
+    wr = E * (S * (3 + 2 * N + (5 + 3 * N) + 1) + 4 + 1)
+    return rd, wr
+
+
+out = {"dir": os.path.basename(d)}
+ks = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if ks:
+    for r in csv.DictReader(open(ks[0])):
+        if "step_kernel" in r["Name"]:
+            out["kernel_trace"] = {k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")}
+for name in ("bench_traced", "bench_plain"):
+    try:
+        line = [l for l in open(os.path.join(d, name + ".json")) if l.startswith("{")][-1]
+        j = json.loads(line)
+        out[name] = {"value": j["value"], "launch_us": j["roofline"]["launch_us"], "frac": j["roofline"]["frac"]}
+    except Exception as e:  # noqa: BLE001
+        out[name] = str(e)
+cal = {}
+for E in (4194304, 65536):
+    f, w = counter("FETCH_SIZE", E), counter("WRITE_SIZE", E)
+    rd, wr = alg_bytes(E)
+    cal[E] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "algorithmic_read_bytes": rd, "algorithmic_write_bytes": wr}
+if cal[4194304]["FETCH_SIZE_KiB"]:
+    k_read = cal[4194304]["algorithmic_read_bytes"] / (cal[4194304]["FETCH_SIZE_KiB"] * 1024)
+    k_write = cal[4194304]["algorithmic_write_bytes"] / (cal[4194304]["WRITE_SIZE_KiB"] * 1024)
+    out["calibration_4M_envs"] = {"k_read": k_read, "write_ratio_alg_over_counter": k_write, **cal[4194304]}
+    if cal[65536]["FETCH_SIZE_KiB"]:
+        rd_b = cal[65536]["FETCH_SIZE_KiB"] * 1024 * k_read
+        wr_b = cal[65536]["WRITE_SIZE_KiB"] * 1024
+        out["headline_65536_envs"] = {**cal[65536], "hbm_read_bytes_per_launch": rd_b,
+                                      "hbm_write_bytes_per_launch": wr_b,
+                                      "hbm_bytes_per_launch": rd_b + wr_b,
+                                      "algorithmic_bytes_per_launch": sum(alg_bytes(65536)) }
+print(json.dumps(out, indent=1))
+json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
