@@ -43,12 +43,12 @@ constexpr int kWavesPerBlock = kBlock / 64;
 // In-kernel stamps: DIAGNOSTIC build only (tools/diag_stamps.py builds libacas2d_hip_diag.so with
 // -DACAS2D_STAMPS).  In the product build ACAS2D_STAMP() is empty and no stamp executes.
 #ifdef ACAS2D_STAMPS
-static __device__ unsigned long long* g_stamps = nullptr;   // [n_waves][8], set by acas2d_debug_set_stamps_*
+static __device__ unsigned long long* g_stamps = nullptr;   // [n_waves][16], set by acas2d_debug_set_stamps_*
 #define ACAS2D_STAMP(k, wave_id, lane_id, drain)                                              \
     do {                                                                                      \
         if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
         if ((lane_id) == 0 && g_stamps)                                                       \
-            g_stamps[(wave_id) * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() \
+            g_stamps[(wave_id) * 16 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() \
                                                                    : __builtin_amdgcn_s_memtime();    \
     } while (0)
 #else
@@ -289,8 +289,11 @@ __device__ __forceinline__ int64_t remap_block() {
 // ---- Philox4x32-10 counter-based reset RNG ---------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#ifndef ACAS2D_EXPERIMENT_PHILOX_ROUNDS
+#define ACAS2D_EXPERIMENT_PHILOX_ROUNDS 10      // diagnostic experiments only; 10 = Philox4x32-10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ACAS2D_EXPERIMENT_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;   // v_mad_u64_u32
         c = U4{(uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0};
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -613,15 +616,21 @@ __device__ __forceinline__ T reset_own_psi(const ResetParams& rp, uint32_t k0, u
 // wave); instead all 64 lanes of the wave take one ENTITY each -- lane 0 the player, lane n the
 // traffic aircraft n-1 (strided by 64 beyond that) -- so the new episode costs one Philox block
 // and one traffic_step() of latency.  Must be called by the whole wave (wave-uniform arguments).
-template <typename T, bool FAST>
+template <typename T, bool FAST, int NS>
 __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetParams& rp, const State<T>& s,
                                                const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
-                                               int64_t e, int N, int lane, T total, int32_t steps,
+                                               int64_t e, int N_dyn, int lane, T total, int32_t steps,
                                                uint32_t episode_prev, T* __restrict__ row) {
+    const int N = NS > 0 ? NS : N_dyn;                   // compile-time for packed shapes
     const int D = 5 + 3 * N;
+#ifdef ACAS2D_STAMPS
+    const int64_t wave_dbg = remap_block() * kWavesPerBlock + (threadIdx.x >> 6);
+#endif
+    ACAS2D_STAMP(8, wave_dbg, lane, false);
     if (io.term_obs) {                                   // the finished episode's last observation
         T* t_row = io.term_obs + e * D;
-        for (int i = lane; i < D; i += 64) t_row[i] = row[i];
+        if constexpr (NS > 0 && 5 + 3 * NS <= 64) { if (lane < D) t_row[lane] = row[lane]; }
+        else { for (int i = lane; i < D; i += 64) t_row[i] = row[i]; }
     }
     const uint32_t episode = episode_prev + 1u;
     wave_lds_fence();                                    // row reads precede its rewrite below
@@ -640,28 +649,34 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
             s.trf_x[i] = tx; s.trf_y[i] = ty; s.trf_psi[i] = tpsi; s.trf_v[i] = tv;
         }
     }
-    for (int n = lane + 63; n < N; n += 64) {            // N > 63 only
-        T x, y, ps, v;
-        reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, ps, v);
-        const int64_t i = e * N + n;
-        s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = ps; s.trf_v[i] = v;
+    if constexpr (NS == 0 || NS > 63) {
+        for (int n = lane + 63; n < N; n += 64) {        // N > 63 only
+            T x, y, ps, v;
+            reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, ps, v);
+            const int64_t i = e * N + n;
+            s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = ps; s.trf_v[i] = v;
+        }
     }
+    ACAS2D_STAMP(9, wave_dbg, lane, false);
     psi_own = __shfl(psi_own, 0, 64);
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
 
+    ACAS2D_STAMP(10, wave_dbg, lane, false);
     // environment.py:44-48: the new episode's first observation (steps becomes 1)
     if (lane >= 1 && lane <= N) {
         T d, dca, vc;
         traffic_step<T, FAST>(p, c, false, tx, ty, tpsi, tv, d, dca, vc);
         put_traffic_obs<T, FAST>(p, row + 5 + 3 * (lane - 1), d, dca, vc);
     }
-    for (int n = lane + 63; n < N; n += 64) {
-        const int64_t i = e * N + n;
-        T x = s.trf_x[i], y = s.trf_y[i], ps = s.trf_psi[i];   // written by this lane above
-        T d, dca, vc;
-        traffic_step<T, FAST>(p, c, false, x, y, ps, s.trf_v[i], d, dca, vc);
-        put_traffic_obs<T, FAST>(p, row + 5 + 3 * n, d, dca, vc);
+    if constexpr (NS == 0 || NS > 63) {
+        for (int n = lane + 63; n < N; n += 64) {
+            const int64_t i = e * N + n;
+            T x = s.trf_x[i], y = s.trf_y[i], ps = s.trf_psi[i];   // written by this lane above
+            T d, dca, vc;
+            traffic_step<T, FAST>(p, c, false, x, y, ps, s.trf_v[i], d, dca, vc);
+            put_traffic_obs<T, FAST>(p, row + 5 + 3 * n, d, dca, vc);
+        }
     }
     if (lane == 0) {
         if (io.ep_return) io.ep_return[e] = total;
@@ -673,22 +688,45 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
         s.total_reward[e] = T(0);
         put_own_obs<T, FAST>(p, row, 1, o.psi, c);
     }
+    ACAS2D_STAMP(11, wave_dbg, lane, false);
 }
 
 // Flush the wave's LDS tile (`count` values, the contiguous slice dst[0 .. count) of obs[E][D])
 // with lane-linear stores: 16 bytes per lane where the slice is 16-byte aligned, else one value.
+// Chunk c (16 bytes, or one value on the unaligned path) is always written by lane c % 64, so a
+// later flush_rows() of the same tile rewrites every address from the SAME work-item (program
+// order, no cross-lane store ordering assumed).
 template <typename T>
 __device__ __forceinline__ void flush_tile(const T* __restrict__ tile, T* __restrict__ dst, int count,
                                            int lane) {
     constexpr int W = 16 / sizeof(T);
     using V = Vec<T, W>;
-    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+    if (__builtin_expect((reinterpret_cast<uintptr_t>(dst) & 15u) == 0, 1)) {
         const int nv = count / W;
         for (int i = lane; i < nv; i += 64)
             reinterpret_cast<V*>(dst)[i] = reinterpret_cast<const V*>(tile)[i];
         for (int i = nv * W + lane; i < count; i += 64) dst[i] = tile[i];
     } else {
         for (int i = lane; i < count; i += 64) dst[i] = tile[i];
+    }
+}
+
+// Re-flush the values [first, last) of the tile (one env's row after its reset) with exactly the
+// chunk -> lane mapping of flush_tile().
+template <typename T>
+__device__ __forceinline__ void flush_rows(const T* __restrict__ tile, T* __restrict__ dst, int count,
+                                           int first, int last, int lane) {
+    constexpr int W = 16 / sizeof(T);
+    using V = Vec<T, W>;
+    if (__builtin_expect((reinterpret_cast<uintptr_t>(dst) & 15u) == 0, 1)) {
+        const int nv = count / W;
+        const int c0 = first / W, c1 = (last + W - 1) / W;           // chunks touching the row
+        for (int c = c0 + ((lane - c0) & 63); c < c1 && c < nv; c += 64)
+            reinterpret_cast<V*>(dst)[c] = reinterpret_cast<const V*>(tile)[c];
+        for (int i = nv * W + lane; i < last; i += 64)               // scalar tail of the tile
+            if (i >= first) dst[i] = tile[i];
+    } else {
+        for (int i = first + ((lane - first) & 63); i < last; i += 64) dst[i] = tile[i];
     }
 }
 
@@ -704,9 +742,11 @@ __device__ __forceinline__ T* wave_tile(int tile_elems) {
 template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST>
 __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetParams rp, State<T> s,
                                                       StepIO<T> io, uint32_t k0, uint32_t k1,
-                                                      int64_t env_offset, int64_t n_envs, int N,
+                                                      int64_t env_offset, int64_t n_envs, int N_arg,
                                                       int tile_elems) {
     const Params<T> p = pinned(p_arg);
+    constexpr int NS = PACKED ? C * G : 0;         // packed shapes: n_traffic is a compile-time constant
+    const int N = PACKED ? NS : N_arg;
     constexpr int EPW = 64 / G;                    // envs per wavefront
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
@@ -784,24 +824,25 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
     }
 
     ACAS2D_STAMP(3, wave, lane, false);
+    // Flush the tile now: the stores drain while finished envs (if any) are being reset below.
+    wave_lds_fence();
+    T* const obs_wave = io.obs + e_wave * D;
+    flush_tile<T>(tile, obs_wave, n_rows * D, lane);
+    ACAS2D_STAMP(4, wave, lane, false);
     if constexpr (AUTO_RESET) {
         // ---- finished envs: one bit per env (its group's lane 0), handled by the whole wave ----
         unsigned long long dm = __ballot(oc != 0 && j == 0);
-        if (dm) {
-            wave_lds_fence();                         // every row of the tile is complete
-            while (dm) {
-                const int src = __ffsll((long long)dm) - 1;           // wave-uniform
-                dm &= dm - 1;
-                const int el_d = src / G;
-                wave_reset_env<T, FAST>(p, rp, s, io, k0, k1, env_offset, e_wave + el_d, N, lane,
+        while (dm) {
+            const int src = __ffsll((long long)dm) - 1;               // wave-uniform
+            dm &= dm - 1;
+            const int el_d = src / G;
+            wave_reset_env<T, FAST, NS>(p, rp, s, io, k0, k1, env_offset, e_wave + el_d, N, lane,
                                         __shfl(total, src, 64), __shfl(steps, src, 64),
                                         (uint32_t)__shfl((int)episode, src, 64), tile + el_d * D);
-            }
+            wave_lds_fence();                         // the fresh row is complete
+            flush_rows<T>(tile, obs_wave, n_rows * D, el_d * D, (el_d + 1) * D, lane);
         }
     }
-    ACAS2D_STAMP(4, wave, lane, false);
-    wave_lds_fence();
-    flush_tile<T>(tile, io.obs + e_wave * D, n_rows * D, lane);
     ACAS2D_STAMP(5, wave, lane, false);
     ACAS2D_STAMP(6, wave, lane, true);
     ACAS2D_STAMP(7, wave, lane, false);

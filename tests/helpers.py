@@ -110,3 +110,28 @@ def replay_baseline(engine, digest, own, trf):
             break
     return dict(outcome=outcome, steps=steps, total_reward=ret, own_last=last, own_sub=sub,
                 trf_sub=tsub, own_first2=first2, unfinished=int(active.sum()))
+
+
+# notebooks/simulation_ACAS2D_PPO_1048576_11_100.ipynb cell 4: `simulation.describe()` of the
+# reference's own 100-episode deterministic evaluation of best_model_1048576_11 (testing_main.py)
+REF_POLICY_EVAL = {
+    "Total Reward": dict(mean=1210.069219, std=69.336537, min=1099.788122, q25=1157.389870,
+                         q50=1200.470752, q75=1245.515314, max=1370.264607),
+    "Time Steps": dict(mean=704.35, std=73.826082, min=634, q25=656, q50=681, q75=721, max=927),
+    "Path Length": dict(mean=1406.70, std=147.652164, min=1266, q25=1310, q50=1360, q75=1440, max=1852),
+}
+
+
+def describe(v):
+    v = np.asarray(v, np.float64)
+    return dict(mean=v.mean(), std=v.std(ddof=1), min=v.min(), q25=np.percentile(v, 25),
+                q50=np.percentile(v, 50), q75=np.percentile(v, 75), max=v.max())
+
+
+def assert_matches_reference_policy_eval(total_reward, steps, path_length, tol=2e-6):
+    """Every printed digit of the reference's table (6 decimals) must be reproduced."""
+    got = {"Total Reward": describe(total_reward), "Time Steps": describe(steps),
+           "Path Length": describe(path_length)}
+    for col, want in REF_POLICY_EVAL.items():
+        for k, w in want.items():
+            assert abs(got[col][k] - w) <= tol * max(1.0, abs(w)), (col, k, got[col][k], w)

@@ -5,8 +5,8 @@ Loads libacas2d_hip_diag.so (make -C gym-acas2d_amd/csrc diag: same kernels + in
 s_memtime / s_memrealtime stamps per wave), runs a few steps and prints, per phase, the
 distribution over waves.  Never quote this build's run time (stamps forbid overlaps the real
 kernel has); read its SHARES.  Stamps per wave: 0 realtime@start, 1 clk@start, 2 clk after all
-loads landed, 3 clk after observe/evaluate + state stores issued, 4 clk after the reset section,
-5 clk after the obs flush is issued, 6 clk after all stores are acknowledged, 7 realtime@end.
+loads landed, 3 clk after observe/evaluate + state stores issued, 4 clk after the obs flush is issued,
+5 clk after the reset section (incl. re-flush of reset rows), 6 clk after all stores are acknowledged, 7 realtime@end.
 """
 import argparse
 import ctypes as C
@@ -27,14 +27,14 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--no-auto-reset", action="store_true")
 args = ap.parse_args()
 
-g.native.LIB_PATH = os.path.join(ROOT, "gym-acas2d_amd", "csrc", "libacas2d_hip_diag.so")
+g.native.LIB_PATH = os.path.join(ROOT, "gym-acas2d_amd", "csrc", os.environ.get("ACAS2D_DIAG_LIB", "libacas2d_hip_diag.so"))
 g.native._lib = None
 L = g.native.lib()
 env = g.ACAS2DVecEnv(args.envs, args.traffic, device="cuda:0", dtype=torch.float32, seed=13,
                      auto_reset=not args.no_auto_reset)
 geo = g.native.launch_geometry(args.envs, args.traffic, 4)
 n_waves = geo["grid_blocks"] * 4
-buf = torch.zeros(n_waves, 8, dtype=torch.int64, device="cuda:0")
+buf = torch.zeros(n_waves, 16, dtype=torch.int64, device="cuda:0")
 L.acas2d_debug_set_stamps_f32.argtypes = [C.c_void_p]
 assert L.acas2d_debug_set_stamps_f32(buf.data_ptr()) == 0
 env.reset()
@@ -42,6 +42,7 @@ gen = torch.Generator(device="cuda:0").manual_seed(0)
 for _ in range(200):                       # get past the start-up transient / into steady resets
     env.step(torch.rand(args.envs, generator=gen, device="cuda:0") * 2 - 1)
 rows = []
+inner = []
 for _ in range(args.steps):
     buf.zero_()
     _, _, done, _ = env.step(torch.rand(args.envs, generator=gen, device="cuda:0") * 2 - 1)
@@ -58,11 +59,15 @@ for _ in range(args.steps):
     span_us = (st[:, 7].max() - t0) / 100.0           # s_memrealtime ticks at 100 MHz
     clk = np.median((st[:, 6] - st[:, 1]) / np.maximum((st[:, 7] - st[:, 0]) / 100.0, 1e-9)) / 1e3   # GHz
     ph = {"start skew us": (st[:, 0] - t0) / 100.0,
-          "loads": st[:, 2] - st[:, 1], "compute": st[:, 3] - st[:, 2], "reset": st[:, 4] - st[:, 3],
-          "flush issue": st[:, 5] - st[:, 4], "store drain": st[:, 6] - st[:, 5],
+          "loads": st[:, 2] - st[:, 1], "compute": st[:, 3] - st[:, 2], "flush issue": st[:, 4] - st[:, 3],
+          "reset": st[:, 5] - st[:, 4], "store drain": st[:, 6] - st[:, 5],
           "wave total": st[:, 6] - st[:, 1]}
+    rs = st[st[:, 8] > 0]
+    if len(rs):
+        inner.append([np.median(rs[:, 8] - rs[:, 4]), np.median(rs[:, 9] - rs[:, 8]), np.median(rs[:, 10] - rs[:, 9]),
+                      np.median(rs[:, 11] - rs[:, 10]), np.median(rs[:, 5] - rs[:, 11])])
     rows.append((span_us, clk, {k: (np.median(v), np.percentile(v, 99), v.max()) for k, v in ph.items()},
-                 wave_done.mean(), np.median((st[:, 4] - st[:, 3])[wave_done]) if wave_done.any() else 0,
+                 wave_done.mean(), np.median((st[:, 5] - st[:, 4])[wave_done]) if wave_done.any() else 0,
                  (st[:, 7] - t0).argmax(), wave_done[(st[:, 7] - t0).argmax()]))
 print("config: %d envs x %d traffic, shape %s, %d waves" % (args.envs, args.traffic, geo, n_waves))
 span = np.array([r[0] for r in rows])
@@ -76,3 +81,7 @@ for k in rows[0][2]:
 print("waves with a finished env: %.1f %%; their reset section: %.0f cycles (median)" %
       (100 * np.mean([r[3] for r in rows]), np.median([r[4] for r in rows])))
 print("last-finishing wave had a finished env in %d of %d launches" % (sum(bool(r[6]) for r in rows), len(rows)))
+if inner:
+    m = np.median(np.array(inner), axis=0)
+    print("reset section of waves with a finished env (last reset in the wave), cycles: ballot/shfl entry %.0f | "
+          "term_obs + Philox + state %.0f | own_context %.0f | traffic obs + stores %.0f | fence + re-flush %.0f" % tuple(m))
