@@ -112,6 +112,25 @@ struct StepIO {
     int32_t* ep_steps;
 };
 
+// Rebase every array on a wave's first env (`e0` wave-uniform, held in SGPRs): inside the kernels
+// all indexing is then  scalar 64-bit base + 32-bit per-lane offset  (global_load ... v_off, s[base]),
+// with no 64-bit VALU address arithmetic.
+template <typename T>
+__device__ __forceinline__ State<T> rebase(const State<T>& s, int64_t e0, int N) {
+    return State<T>{s.own_x + e0, s.own_y + e0, s.own_psi + e0, s.own_v + e0, s.goal_x + e0, s.goal_y + e0,
+                    s.trf_x + e0 * N, s.trf_y + e0 * N, s.trf_psi + e0 * N, s.trf_v + e0 * N,
+                    s.steps + e0, s.total_reward + e0, s.status + e0, s.episode + e0};
+}
+template <typename T>
+__device__ __forceinline__ StepIO<T> rebase(const StepIO<T>& io, int64_t e0, int D) {
+    return StepIO<T>{io.actions + e0, io.obs + e0 * D, io.reward + e0, io.done + e0, io.outcome + e0,
+                     io.term_obs ? io.term_obs + e0 * D : nullptr, io.ep_return ? io.ep_return + e0 : nullptr,
+                     io.ep_steps ? io.ep_steps + e0 : nullptr};
+}
+// Wave index within the workgroup as a scalar (threadIdx.x >> 6 is wave-uniform, but only
+// readfirstlane tells the compiler so).
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // ---- scalar math, one overload set per element type ----------------------------------------------
 __device__ __forceinline__ void m_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
 __device__ __forceinline__ void m_sincos(double x, double* s, double* c) { sincos(x, s, c); }
@@ -174,6 +193,23 @@ __device__ __forceinline__ T py_mod360(T a) {
         if (r != T(0)) { if (r < T(0)) r += m; } else { r = T(0); }
     }
     return r;
+}
+
+// FAST formulation: the branch-free window alone.  Exact for a in (-360, 720), i.e. for every
+// heading the engine itself produces (|d psi| < 1 degree per step from [0, 360]); headings injected
+// outside that window are wrapped by the EXACT (float64) build only.
+template <typename T>
+__device__ __forceinline__ T wrap360_window(T a) {
+    const T m = T(360);
+    T r = a;
+    r = (a >= m) ? a - m : r;
+    r = (a < T(0)) ? a + m : r;
+    return r;
+}
+template <typename T, bool FAST>
+__device__ __forceinline__ T wrap360(T a) {
+    if constexpr (FAST) return wrap360_window(a);
+    else return py_mod360(a);
 }
 
 // (deg / 360.0) * 2 * math.pi, left to right.  aircraft.py:23, kinematics.py:29,33,46,59,70
@@ -305,6 +341,11 @@ __device__ __forceinline__ double uniform(double a, double b, double u) {
 #pragma clang fp contract(off)   // same rounding in the f32 (contract=fast) and f64 builds
     return a + (b - a) * u;
 }
+// float32 build, in-step reset only: the same draws evaluated in float32 (24 random bits per
+// uniform) -- equal to the float64 evaluation rounded to float32 up to 1-2 ulp, at a fraction of
+// the latency of the float64 path on the kernel's critical tail.
+__device__ __forceinline__ float u01f(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float uniformf(float a, float b, float u) { return fmaf(b - a, u, a); }
 
 // ---- per-lane vector of C traffic values ---------------------------------------------------------
 template <typename T, int C>
@@ -340,7 +381,7 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
     c.x = o.x; c.y = o.y; c.v = o.v;
     if constexpr (FAST) {
         f_sincos_rev(o.psi * Const<T>::inv360, &c.so, &c.co);
-        T psi1 = py_mod360(o.psi + (o.a_lat * f_rcp(o.v)) * p.dt);
+        T psi1 = wrap360_window(o.psi + (o.a_lat * f_rcp(o.v)) * p.dt);
         T s1, c1;
         f_sincos_rev(psi1 * Const<T>::inv360, &s1, &c1);
         const T vdt = o.v * p.dt;
@@ -372,7 +413,7 @@ template <typename T, bool FAST>
 __device__ __forceinline__ void traffic_step(const Params<T>& p, const OwnCtx<T>& c, bool move, T& tx,
                                              T& ty, T& tpsi, T tv, T& d, T& dca, T& vc) {
     // aircraft.py:16-26 with a_lat = 0: psi = psi % 360, then the Euler step
-    tpsi = py_mod360(tpsi);
+    tpsi = wrap360<T, FAST>(tpsi);
     T st, ct;
     if constexpr (FAST) {
         f_sincos_rev(tpsi * Const<T>::inv360, &st, &ct);
@@ -445,7 +486,7 @@ struct Traffic {
     Vec<T, C> x, y, psi, v;
 };
 template <typename T, int C>
-__device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int64_t i0) {
+__device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int i0) {
     using V = Vec<T, C>;
     Traffic<T, C> t;
     t.x = *reinterpret_cast<const V*>(s.trf_x + i0);
@@ -463,7 +504,7 @@ __device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int64_t
 // loads / stores aircraft by aircraft.
 template <typename T, int C, int G, bool PACKED, bool FAST>
 __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
-                                           int64_t e, int j, int N, int32_t steps, bool move,
+                                           int e, int j, int N, int32_t steps, bool move,
                                            Traffic<T, C>& tr, T* __restrict__ row) {
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
     Seen<T> r;
@@ -472,7 +513,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
     T vc0 = T(0), dc0 = T(0);
     if constexpr (PACKED) {
         using V = Vec<T, C>;
-        const int64_t i0 = e * N + (int64_t)j * C;
+        const int i0 = e * N + j * C;
         bool psi_changed = false;
 #pragma unroll
         for (int k = 0; k < C; ++k) {
@@ -491,7 +532,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
         }
     } else {
         for (int n = j; n < N; n += G) {
-            const int64_t i = e * N + n;
+            const int i = e * N + n;
             T tx = s.trf_x[i], ty = s.trf_y[i], tpsi = s.trf_psi[i];
             const T tv = s.trf_v[i], psi_in = tpsi;
             T d, dca, vc;
@@ -540,7 +581,7 @@ __device__ __forceinline__ void reset_traffic(const ResetParams& rp, uint32_t k0
 
 template <typename T, int C, int G, bool PACKED>
 __device__ __forceinline__ Own<T> reset_env(const ResetParams& rp, const State<T>& s, uint32_t k0,
-                                            uint32_t k1, uint64_t gid, uint32_t episode, int64_t e,
+                                            uint32_t k1, uint64_t gid, uint32_t episode, int e,
                                             int j, int N, Traffic<T, C>& tr) {
 #pragma clang fp contract(off)   // float64 here in both builds: a seed names the same episode
     const uint32_t g_lo = (uint32_t)gid, g_hi = (uint32_t)(gid >> 32);
@@ -558,14 +599,14 @@ __device__ __forceinline__ Own<T> reset_env(const ResetParams& rp, const State<T
 #pragma unroll
         for (int k = 0; k < C; ++k)
             reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, j * C + k, tr.x.v[k], tr.y.v[k], tr.psi.v[k], tr.v.v[k]);
-        const int64_t i0 = e * N + (int64_t)j * C;
+        const int i0 = e * N + j * C;
         *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
         *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
         *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;
         *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
     } else {
         for (int n = j; n < N; n += G) {
-            const int64_t i = e * N + n;
+            const int i = e * N + n;
             T x, y, psi, v;
             reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, psi, v);
             s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = psi; s.trf_v[i] = v;
@@ -587,6 +628,18 @@ __device__ __forceinline__ void reset_entity(const ResetParams& rp, uint32_t k0,
                                              T& ov) {
 #pragma clang fp contract(off)
     const U4 w = philox4x32_10(U4{g_lo, g_hi, episode, (uint32_t)ent}, k0, k1);
+    if constexpr (sizeof(T) == 4) {
+        const bool own = ent == 0, first = ent == 1;
+        const float down = (float)(w.x >> 31), u_psi = u01f(w.z);
+        const float jitter = own ? (float)rp.own_heading_jitter : (float)rp.t0_heading_jitter;
+        const float base = own ? (float)rp.own_heading0 : fmaf(down, (float)rp.t0_heading_step, (float)rp.t0_heading_base);
+        const float psi_special = wrap360_window(base + uniformf(-jitter, jitter, u_psi));
+        opsi = (own || first) ? psi_special : 360.0f * u_psi;
+        ox = first ? (float)rp.t0_x : (float)rp.tn_x_max * u01f(w.x);
+        oy = first ? fmaf(down, (float)rp.t0_y_span, (float)rp.t0_y_base) : (float)rp.tn_y_max * u01f(w.y);
+        ov = uniformf((float)rp.speed_factor_min, (float)rp.speed_factor_max, u01f(w.w)) * (float)rp.airspeed;
+        return;
+    }
     const double u_psi = u01(w.z);
     const bool own = ent == 0, first = ent == 1;
     const double down = (double)(w.x >> 31);
@@ -618,8 +671,8 @@ __device__ __forceinline__ T reset_own_psi(const ResetParams& rp, uint32_t k0, u
 // and one traffic_step() of latency.  Must be called by the whole wave (wave-uniform arguments).
 template <typename T, bool FAST, int NS>
 __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetParams& rp, const State<T>& s,
-                                               const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
-                                               int64_t e, int N_dyn, int lane, T total, int32_t steps,
+                                               const StepIO<T>& io, uint32_t k0, uint32_t k1, uint64_t gid,
+                                               int e, int N_dyn, int lane, T total, int32_t steps,
                                                uint32_t episode_prev, T* __restrict__ row) {
     const int N = NS > 0 ? NS : N_dyn;                   // compile-time for packed shapes
     const int D = 5 + 3 * N;
@@ -634,7 +687,6 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
     }
     const uint32_t episode = episode_prev + 1u;
     wave_lds_fence();                                    // row reads precede its rewrite below
-    const uint64_t gid = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)gid, g_hi = (uint32_t)(gid >> 32);
 
     // entity `lane`: the player (lane 0) or traffic lane-1; further traffic in strides of 64.
@@ -645,7 +697,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
         if (lane == 0) {
             psi_own = tpsi;
         } else {
-            const int64_t i = e * N + (lane - 1);
+            const int i = e * N + (lane - 1);
             s.trf_x[i] = tx; s.trf_y[i] = ty; s.trf_psi[i] = tpsi; s.trf_v[i] = tv;
         }
     }
@@ -653,7 +705,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
         for (int n = lane + 63; n < N; n += 64) {        // N > 63 only
             T x, y, ps, v;
             reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, ps, v);
-            const int64_t i = e * N + n;
+            const int i = e * N + n;
             s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = ps; s.trf_v[i] = v;
         }
     }
@@ -671,7 +723,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
     }
     if constexpr (NS == 0 || NS > 63) {
         for (int n = lane + 63; n < N; n += 64) {
-            const int64_t i = e * N + n;
+            const int i = e * N + n;
             T x = s.trf_x[i], y = s.trf_y[i], ps = s.trf_psi[i];   // written by this lane above
             T d, dca, vc;
             traffic_step<T, FAST>(p, c, false, x, y, ps, s.trf_v[i], d, dca, vc);
@@ -740,8 +792,8 @@ __device__ __forceinline__ T* wave_tile(int tile_elems) {
 
 // ACAS2DEnv.step(), environment.py:29-42.
 template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST>
-__global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetParams rp, State<T> s,
-                                                      StepIO<T> io, uint32_t k0, uint32_t k1,
+__global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetParams rp, State<T> s_arg,
+                                                      StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
                                                       int tile_elems) {
     const Params<T> p = pinned(p_arg);
@@ -750,15 +802,18 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
     constexpr int EPW = 64 / G;                    // envs per wavefront
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
-    const int64_t wave = remap_block() * kWavesPerBlock + (threadIdx.x >> 6);
-    const int64_t e_wave = wave * EPW;             // first env of this wave
+    const int wib = wave_in_block();
+    const int64_t wave = remap_block() * kWavesPerBlock + wib;
+    const int64_t e_wave = wave * EPW;             // first env of this wave (scalar)
     if (e_wave >= n_envs) return;                  // whole wave idle
-    const int64_t e = e_wave + el;
-    const bool active = e < n_envs;                // whole groups are active or not
     const int D = 5 + 3 * N;
-    T* tile = wave_tile<T>(tile_elems);
-    T* row = tile + el * D;
     const int n_rows = (int)((n_envs - e_wave) < EPW ? (n_envs - e_wave) : EPW);
+    const bool active = el < n_rows;               // whole groups are active or not
+    const State<T> s = rebase(s_arg, e_wave, N);   // everything below indexes envs by `el`
+    const StepIO<T> io = rebase(io_arg, e_wave, D);
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* tile = reinterpret_cast<T*>(lds_raw) + wib * tile_elems;
+    T* row = tile + el * D;
 
     ACAS2D_STAMP(0, wave, lane, false);
     ACAS2D_STAMP(1, wave, lane, false);
@@ -770,20 +825,20 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
     if (active) {
         // ---- every load of this lane up front: one memory round trip, all requests in flight ----
         Traffic<T, C> tr;
-        if constexpr (PACKED) tr = load_traffic<T, C>(s, e * N + (int64_t)j * C);
-        o = Own<T>{s.own_x[e], s.own_y[e], s.own_psi[e], s.own_v[e], T(0), s.goal_x[e], s.goal_y[e]};
-        const T action = io.actions[e];
-        steps = s.steps[e];
-        total = s.total_reward[e];
+        if constexpr (PACKED) tr = load_traffic<T, C>(s, el * N + j * C);
+        o = Own<T>{s.own_x[el], s.own_y[el], s.own_psi[el], s.own_v[el], T(0), s.goal_x[el], s.goal_y[el]};
+        const T action = io.actions[el];
+        steps = s.steps[el];
+        total = s.total_reward[el];
         bool frozen = false;
-        if constexpr (AUTO_RESET) episode = s.episode[e];
-        else frozen = s.status[e] != 0;                                   // game.py:243-245
+        if constexpr (AUTO_RESET) episode = s.episode[el];
+        else frozen = s.status[el] != 0;                                   // game.py:243-245
         ACAS2D_STAMP(2, wave, lane, true);
 
         // game.py:225 + aircraft.py:16-26 for the player
         o.a_lat = action * p.acc_lat_limit;
         if constexpr (FAST) {
-            o.psi = py_mod360(o.psi + o.a_lat * f_rcp(o.v));   // (a_lat / (v dt)) dt
+            o.psi = wrap360_window(o.psi + o.a_lat * f_rcp(o.v));   // (a_lat / (v dt)) dt
             T sn, cs;
             f_sincos_rev(o.psi * Const<T>::inv360, &sn, &cs);
             const T vdt = o.v * p.dt;
@@ -798,7 +853,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
             o.y = o.y + ((o.v * sn) * p.dt);
         }
         steps += 1;                                                       // game.py:197
-        Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, e, j, N, steps, !frozen, tr, row);
+        Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row);
 
         // game.py:249-292 evaluate()
         T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
@@ -811,14 +866,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
         oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
         if (j == 0) {
             total = total + rw;                                           // :287
-            io.reward[e] = rw;
-            io.done[e] = oc != 0;
-            io.outcome[e] = oc;
+            io.reward[el] = rw;
+            io.done[el] = oc != 0;
+            io.outcome[el] = oc;
             if (oc == 0 || !AUTO_RESET) {
-                s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi;
-                s.steps[e] = steps;
-                s.total_reward[e] = total;
-                if constexpr (!AUTO_RESET) { if (oc) s.status[e] = oc; }
+                s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
+                s.steps[el] = steps;
+                s.total_reward[el] = total;
+                if constexpr (!AUTO_RESET) { if (oc) s.status[el] = oc; }
             }
         }
     }
@@ -826,7 +881,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
     ACAS2D_STAMP(3, wave, lane, false);
     // Flush the tile now: the stores drain while finished envs (if any) are being reset below.
     wave_lds_fence();
-    T* const obs_wave = io.obs + e_wave * D;
+    T* const obs_wave = io.obs;
     flush_tile<T>(tile, obs_wave, n_rows * D, lane);
     ACAS2D_STAMP(4, wave, lane, false);
     if constexpr (AUTO_RESET) {
@@ -836,7 +891,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
             const int src = __ffsll((long long)dm) - 1;               // wave-uniform
             dm &= dm - 1;
             const int el_d = src / G;
-            wave_reset_env<T, FAST, NS>(p, rp, s, io, k0, k1, env_offset, e_wave + el_d, N, lane,
+            wave_reset_env<T, FAST, NS>(p, rp, s, io, k0, k1, (uint64_t)(env_offset + e_wave + el_d), el_d, N, lane,
                                         __shfl(total, src, 64), __shfl(steps, src, 64),
                                         (uint32_t)__shfl((int)episode, src, 64), tile + el_d * D);
             wave_lds_fence();                         // the fresh row is complete
@@ -850,7 +905,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
 
 // ACAS2DEnv.reset(), environment.py:44-48.
 template <typename T, int C, int G, bool PACKED, bool FAST>
-__global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams rp, State<T> s,
+__global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams rp, State<T> s_arg,
                                                        const uint8_t* __restrict__ mask, T* obs,
                                                        int do_init, uint32_t k0, uint32_t k1,
                                                        int64_t env_offset, int64_t n_envs, int N,
@@ -858,34 +913,36 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams 
     constexpr int EPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;
-    const int64_t wave = remap_block() * kWavesPerBlock + (threadIdx.x >> 6);
-    const int64_t e = wave * EPW + el;
-    if (e >= n_envs) return;
-    if (mask && !mask[e]) return;
+    const int wib = wave_in_block();
+    const int64_t e_wave = (remap_block() * kWavesPerBlock + wib) * EPW;
+    if (e_wave + el >= n_envs) return;
     const int D = 5 + 3 * N;
-    T* row = wave_tile<T>(tile_elems) + el * D;
+    const State<T> s = rebase(s_arg, e_wave, N);
+    if (mask && !mask[e_wave + el]) return;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* row = reinterpret_cast<T*>(lds_raw) + wib * tile_elems + el * D;
     Own<T> o;
     Traffic<T, C> tr;
     int32_t steps;
     if (do_init) {
-        o = reset_env<T, C, G, PACKED>(rp, s, k0, k1, (uint64_t)(env_offset + e), s.episode[e], e, j, N, tr);
+        o = reset_env<T, C, G, PACKED>(rp, s, k0, k1, (uint64_t)(env_offset + e_wave + el), s.episode[el], el, j, N, tr);
         steps = 0;
     } else {
-        if constexpr (PACKED) tr = load_traffic<T, C>(s, e * N + (int64_t)j * C);
-        o = Own<T>{s.own_x[e], s.own_y[e], s.own_psi[e], s.own_v[e], T(0), s.goal_x[e], s.goal_y[e]};
-        steps = s.steps[e];
+        if constexpr (PACKED) tr = load_traffic<T, C>(s, el * N + j * C);
+        o = Own<T>{s.own_x[el], s.own_y[el], s.own_psi[el], s.own_v[el], T(0), s.goal_x[el], s.goal_y[el]};
+        steps = s.steps[el];
     }
     if (obs) {
         steps += 1;
-        observe<T, C, G, PACKED, FAST>(p, s, o, e, j, N, steps, false, tr, row);
+        observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row);
         wave_lds_fence();
-        T* dst = obs + e * D;                         // masked rows are not contiguous: per-row copy
+        T* dst = obs + (e_wave + el) * D;             // masked rows are not contiguous: per-row copy
         for (int i = j; i < D; i += G) dst[i] = row[i];
     }
     if (j == 0) {
-        s.steps[e] = steps;
-        s.total_reward[e] = T(0);
-        s.status[e] = 0;
+        s.steps[el] = steps;
+        s.total_reward[el] = T(0);
+        s.status[el] = 0;
     }
 }
 
