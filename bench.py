@@ -91,6 +91,8 @@ def load_traffic(envs, traffic, dtype):
 def main():
     args = parse()
     import gym_acas2d_amd as g
+    if os.environ.get("ACAS2D_BENCH_LIB"):        # diagnostic builds (tools/): ablation / stamps
+        g.native.LIB_PATH = os.path.join(ROOT, "gym-acas2d_amd", "csrc", os.environ["ACAS2D_BENCH_LIB"])
     rank, local_rank, world = g.sharding.dist_env()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:

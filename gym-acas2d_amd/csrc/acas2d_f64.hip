@@ -2,7 +2,9 @@
 // fused multiply-adds are the explicit ones that mirror the reference's OpenBLAS ddot
 // (kinematics.py:11,77).
 #define ACAS2D_PACKED_SHAPES(X) X(3, 1) X(2, 1) X(2, 4) X(4, 2) X(2, 32) X(4, 16)
-namespace acas2d { constexpr bool kFast = false; }
+namespace acas2d {
+constexpr bool kFast = false;
+}
 #include "acas2d_launch.inl"
 namespace acas2d {
 template int launch_step<double>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, uint32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);

@@ -305,12 +305,27 @@ __device__ __forceinline__ T group_bcast0(T v) {
     return __shfl(v, (int)(threadIdx.x & 63u) & ~(G - 1), 64);
 }
 
-// Orders this wave's LDS writes before its later LDS reads (the tile is private to the wave and
-// a wave's DS instructions execute in issue order, so only the COMPILER must be held back).
+// Value of `v` in lane `src` (wave-uniform, so a v_readlane instead of a ds_bpermute round trip).
+__device__ __forceinline__ int lane_value(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float lane_value(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ double lane_value(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Orders this wave's LDS writes before its later LDS reads.  The tile is private to the wave and
+// a wave's DS instructions execute in issue order, so only the COMPILER must be held back: a
+// memory clobber + wave_barrier.  (NOT __builtin_amdgcn_fence(..., "wavefront"): hipcc lowers that
+// with s_waitcnt vmcnt(0), which stalled a resetting wave on the acknowledgement of every store
+// it had in flight -- in the middle of the chip-wide write burst.)
 __device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 // XCD-aware block remap: blocks are dealt round-robin over the 8 XCDs, so give each XCD one
@@ -353,6 +368,11 @@ struct alignas((C * sizeof(T)) % 16 == 0 ? 16 : ((C * sizeof(T)) % 8 == 0 ? 8 : 
     T v[C];
 };
 
+template <typename T, int W>
+__device__ __forceinline__ void store_chunk(Vec<T, W>* dst, const Vec<T, W>& v);
+template <typename T, int W>
+__device__ __forceinline__ void store_chunk_nt_any(Vec<T, W>* dst, const Vec<T, W>& v);
+
 // ---- one env's player, as every lane of its group sees it ------------------------------------------
 template <typename T>
 struct Own {
@@ -379,6 +399,11 @@ template <typename T, bool FAST>
 __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T>& o) {
     OwnCtx<T> c;
     c.x = o.x; c.y = o.y; c.v = o.v;
+#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 1     // diagnostic: arithmetic stubbed out
+    c.co = o.psi; c.so = o.v; c.v1x = o.a_lat; c.v1y = o.gx; c.x1 = o.gy; c.y1 = p.dt;
+    c.d_goal = o.x + T(1000); c.h_goal = o.psi; c.d_dev = o.y;
+    return c;
+#endif
     if constexpr (FAST) {
         f_sincos_rev(o.psi * Const<T>::inv360, &c.so, &c.co);
         T psi1 = wrap360_window(o.psi + (o.a_lat * f_rcp(o.v)) * p.dt);
@@ -406,20 +431,38 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
     return c;
 }
 
-// One traffic aircraft: the traffic half of game.py:222-247 action() (when `move`) and the raw
-// (un-normalised) values behind its three observation entries of game.py:205-210.
-// In/out: tx, ty (moved), tpsi (wrapped).
+// One traffic aircraft, part 1 -- the traffic half of game.py:222-247 action(): wrap the heading,
+// sin / cos of it, Euler step when `move`.  In/out: tx, ty (moved), tpsi (wrapped); out: st, ct.
 template <typename T, bool FAST>
-__device__ __forceinline__ void traffic_step(const Params<T>& p, const OwnCtx<T>& c, bool move, T& tx,
-                                             T& ty, T& tpsi, T tv, T& d, T& dca, T& vc) {
+__device__ __forceinline__ void traffic_move(const Params<T>& p, bool move, T& tx, T& ty, T& tpsi, T tv,
+                                             T& st, T& ct) {
     // aircraft.py:16-26 with a_lat = 0: psi = psi % 360, then the Euler step
     tpsi = wrap360<T, FAST>(tpsi);
-    T st, ct;
     if constexpr (FAST) {
         f_sincos_rev(tpsi * Const<T>::inv360, &st, &ct);
         const T tvdt = tv * p.dt;
+        if (move) { tx = m_fma(tvdt, ct, tx); ty = m_fma(tvdt, st, ty); }
+    } else {
+        m_sincos(deg2rad_ref(tpsi), &st, &ct);
+        if (move) {
+            tx = tx + ((tv * ct) * p.dt);
+            ty = ty + ((tv * st) * p.dt);
+        }
+    }
+}
+
+// Part 2 -- the raw (un-normalised) values behind the three observation entries of
+// game.py:205-210 for an aircraft at (tx, ty) with heading sin / cos (st, ct).
+template <typename T, bool FAST>
+__device__ __forceinline__ void traffic_observe(const Params<T>& p, const OwnCtx<T>& c, T tx, T ty, T tv,
+                                                T st, T ct, T& d, T& dca, T& vc) {
+#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 1     // diagnostic: arithmetic stubbed out
+    d = tx + T(1000); dca = ty + c.v1x; vc = tv + st + c.x1 + c.y1 + c.v1y + ct;
+    return;
+#endif
+    if constexpr (FAST) {
+        const T tvdt = tv * p.dt;
         const T v2x = tvdt * ct, v2yt = tvdt * st;
-        if (move) { tx += v2x; ty += v2yt; }
         const T dx = tx - c.x, dy = ty - c.y;
         d = f_sqrt(m_fma(dy, dy, dx * dx));
         // kinematics.py:40-49: d sin(a_rel - arctan(v12y / v12x))
@@ -434,11 +477,6 @@ __device__ __forceinline__ void traffic_step(const Params<T>& p, const OwnCtx<T>
         const T ax = c.v1x - v2x, ay = c.v1y - v2y, bx = c.x1 - x2, by = c.y1 - y2;
         vc = (m_fma(ay, by, ax * bx) * f_rsq(m_fma(by, by, bx * bx))) * p.inv_dt;
     } else {
-        m_sincos(deg2rad_ref(tpsi), &st, &ct);
-        if (move) {
-            tx = tx + ((tv * ct) * p.dt);
-            ty = ty + ((tv * st) * p.dt);
-        }
         d = distance(c.x, c.y, tx, ty);
         // kinematics.py:40-49 distance_closest_approach (arctan of a quotient, signed result)
         const T a_rel_rad = deg2rad_ref(relative_angle(c.x, c.y, tx, ty));
@@ -450,6 +488,15 @@ __device__ __forceinline__ void traffic_step(const Params<T>& p, const OwnCtx<T>
         const T ax = c.v1x - v2x, ay = c.v1y - v2y, bx = c.x1 - x2, by = c.y1 - y2;
         vc = (m_fma(ay, by, ax * bx) / distance(c.x1, c.y1, x2, y2)) / p.dt;
     }
+}
+
+// Both parts for one aircraft (generic walk, reset path).
+template <typename T, bool FAST>
+__device__ __forceinline__ void traffic_step(const Params<T>& p, const OwnCtx<T>& c, bool move, T& tx,
+                                             T& ty, T& tpsi, T tv, T& d, T& dca, T& vc) {
+    T st, ct;
+    traffic_move<T, FAST>(p, move, tx, ty, tpsi, tv, st, ct);
+    traffic_observe<T, FAST>(p, c, tx, ty, tv, st, ct, d, dca, vc);
 }
 
 // game.py:199-203: the five player entries of the observation into the LDS row.
@@ -473,6 +520,10 @@ __device__ __forceinline__ void put_own_obs(const Params<T>& p, T* row, int32_t 
 // game.py:205-210: the three normalised entries of one traffic aircraft into the LDS row.
 template <typename T, bool FAST>
 __device__ __forceinline__ void put_traffic_obs(const Params<T>& p, T* q, T d, T dca, T vc) {
+#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 3
+    asm volatile("" :: "v"(d), "v"(dca), "v"(vc));
+    return;
+#endif
     if constexpr (FAST) {
         q[0] = d * p.inv_d_sep_max; q[1] = dca * p.inv_d_cpa_max; q[2] = vc * p.inv_v_closing_max;
     } else {
@@ -514,21 +565,39 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
     if constexpr (PACKED) {
         using V = Vec<T, C>;
         const int i0 = e * N + j * C;
+        // Move the whole block first and store it at once: the state write-back (half of the
+        // kernel's store bytes besides obs) then drains underneath the observation arithmetic
+        // instead of joining the write burst at the end of the wave.
         bool psi_changed = false;
+        T st[C], ct[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const T psi_in = tr.psi.v[k];
+            traffic_move<T, FAST>(p, move, tr.x.v[k], tr.y.v[k], tr.psi.v[k], tr.v.v[k], st[k], ct[k]);
+            psi_changed |= (tr.psi.v[k] != psi_in);
+        }
+#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 5
+        asm volatile("" :: "v"(tr.x.v[0]), "v"(tr.y.v[0]));
+        if (false) {
+#else
+        if (move) {
+#endif
+#if ACAS2D_OBS_STORE >= 2
+            store_chunk<T, C>(reinterpret_cast<V*>(s.trf_x + i0), tr.x);
+            store_chunk_nt_any<T, C>(reinterpret_cast<V*>(s.trf_y + i0), tr.y);
+#else
+            *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
+            *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+#endif
+            if (psi_changed) *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;   // injected headings >= 360 only
+        }
 #pragma unroll
         for (int k = 0; k < C; ++k) {
             T d, dca, vc;
-            const T psi_in = tr.psi.v[k];
-            traffic_step<T, FAST>(p, c, move, tr.x.v[k], tr.y.v[k], tr.psi.v[k], tr.v.v[k], d, dca, vc);
-            psi_changed |= (tr.psi.v[k] != psi_in);
+            traffic_observe<T, FAST>(p, c, tr.x.v[k], tr.y.v[k], tr.v.v[k], st[k], ct[k], d, dca, vc);
             coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
             put_traffic_obs<T, FAST>(p, row + 5 + 3 * (j * C + k), d, dca, vc);
             if (k == 0) { vc0 = vc; dc0 = dca; }
-        }
-        if (move) {
-            *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
-            *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
-            if (psi_changed) *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;   // injected headings >= 360 only
         }
     } else {
         for (int n = j; n < N; n += G) {
@@ -710,7 +779,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
         }
     }
     ACAS2D_STAMP(9, wave_dbg, lane, false);
-    psi_own = __shfl(psi_own, 0, 64);
+    psi_own = lane_value(psi_own, 0);
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
 
@@ -748,6 +817,28 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
 // Chunk c (16 bytes, or one value on the unaligned path) is always written by lane c % 64, so a
 // later flush_rows() of the same tile rewrites every address from the SAME work-item (program
 // order, no cross-lane store ordering assumed).
+// 16-byte store of an observation chunk.  ACAS2D_OBS_STORE selects the cache policy (tuning
+// knob): 0 plain, 1 non-temporal (streaming: obs is written once and never re-read here;
+// measured 8.11 -> 7.7 us per launch at 65 536 x 8 and +4 % at 4 M envs), 2 also the traffic block.
+#ifndef ACAS2D_OBS_STORE
+#define ACAS2D_OBS_STORE 1
+#endif
+template <typename T, int W>
+__device__ __forceinline__ void store_chunk(Vec<T, W>* dst, const Vec<T, W>& v) {
+#if ACAS2D_OBS_STORE >= 1
+    typedef T NV __attribute__((ext_vector_type(W)));
+    NV x;
+#pragma unroll
+    for (int k = 0; k < W; ++k) x[k] = v.v[k];
+    __builtin_nontemporal_store(x, reinterpret_cast<NV*>(dst));
+#else
+    *dst = v;
+#endif
+}
+
+template <typename T, int W>
+__device__ __forceinline__ void store_chunk_nt_any(Vec<T, W>* dst, const Vec<T, W>& v) { store_chunk<T, W>(dst, v); }
+
 template <typename T>
 __device__ __forceinline__ void flush_tile(const T* __restrict__ tile, T* __restrict__ dst, int count,
                                            int lane) {
@@ -756,7 +847,7 @@ __device__ __forceinline__ void flush_tile(const T* __restrict__ tile, T* __rest
     if (__builtin_expect((reinterpret_cast<uintptr_t>(dst) & 15u) == 0, 1)) {
         const int nv = count / W;
         for (int i = lane; i < nv; i += 64)
-            reinterpret_cast<V*>(dst)[i] = reinterpret_cast<const V*>(tile)[i];
+            store_chunk<T, W>(reinterpret_cast<V*>(dst) + i, reinterpret_cast<const V*>(tile)[i]);
         for (int i = nv * W + lane; i < count; i += 64) dst[i] = tile[i];
     } else {
         for (int i = lane; i < count; i += 64) dst[i] = tile[i];
@@ -853,6 +944,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
             o.y = o.y + ((o.v * sn) * p.dt);
         }
         steps += 1;                                                       // game.py:197
+        // `episode` is first USED in the reset loop far below; without this use the compiler waits
+        // for its load there with s_waitcnt vmcnt(0) -- i.e. for every store issued since.
+        asm volatile("" : "+v"(episode));
         Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row);
 
         // game.py:249-292 evaluate()
@@ -864,7 +958,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
         if (at_goal) rw += p.reward_goal;                                 // :283-284
         // game.py:294-314 is_done(): timeout > collision > goal
         oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
+#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 4
+        asm volatile("" :: "v"(rw), "v"(o.x), "v"(o.y), "v"(o.psi));
+        if (false) {
+#else
         if (j == 0) {
+#endif
             total = total + rw;                                           // :287
             io.reward[el] = rw;
             io.done[el] = oc != 0;
@@ -882,18 +981,20 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
     // Flush the tile now: the stores drain while finished envs (if any) are being reset below.
     wave_lds_fence();
     T* const obs_wave = io.obs;
+#if !defined(ACAS2D_ABLATE) || ACAS2D_ABLATE < 2
     flush_tile<T>(tile, obs_wave, n_rows * D, lane);
+#endif
     ACAS2D_STAMP(4, wave, lane, false);
     if constexpr (AUTO_RESET) {
         // ---- finished envs: one bit per env (its group's lane 0), handled by the whole wave ----
         unsigned long long dm = __ballot(oc != 0 && j == 0);
         while (dm) {
-            const int src = __ffsll((long long)dm) - 1;               // wave-uniform
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);   // wave-uniform
             dm &= dm - 1;
             const int el_d = src / G;
             wave_reset_env<T, FAST, NS>(p, rp, s, io, k0, k1, (uint64_t)(env_offset + e_wave + el_d), el_d, N, lane,
-                                        __shfl(total, src, 64), __shfl(steps, src, 64),
-                                        (uint32_t)__shfl((int)episode, src, 64), tile + el_d * D);
+                                        lane_value(total, src), lane_value(steps, src),
+                                        (uint32_t)lane_value((int)episode, src), tile + el_d * D);
             wave_lds_fence();                         // the fresh row is complete
             flush_rows<T>(tile, obs_wave, n_rows * D, el_d * D, (el_d + 1) * D, lane);
         }
