@@ -46,7 +46,11 @@ def parse():
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
                     help="replay the step launches from a captured hipGraph (default) or launch eagerly")
     ap.add_argument("--chunk", type=int, default=100, help="steps per captured graph / action rows")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--device", type=int, default=None, help="rehearsal only: force this GPU index on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the secondary fused-rollout measurement")
+    ap.add_argument("--rollout-steps", type=int, default=200)
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic: latch outcomes instead of resetting")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -99,9 +103,10 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    g.sharding.init_process_group("nccl")
+    dev_index = local_rank if args.device is None else args.device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    g.sharding.init_process_group(args.backend)
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     E, N, K, W = args.envs, args.traffic, args.steps, args.warmup
 
@@ -156,6 +161,36 @@ def main():
     dev_ms = g.sharding.max_over_ranks(dev_ms, device=dev)
     episodes = g.sharding.sum_over_ranks(float(env.episode.to(torch.int64).sum().item()), device=dev)
 
+    # ---- secondary: the same workload through acas2d_rollout_* (T steps fused per launch) ----
+    fused = None
+    if not args.no_rollout and not args.no_auto_reset:
+        try:
+            T = args.rollout_steps
+            act = torch.rand(T, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
+            out = env.rollout(act)
+            torch.cuda.synchronize()
+            barrier()
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            r0.record()
+            for _ in range(reps):
+                out = env.rollout(act, out=out)
+            r1.record()
+            torch.cuda.synchronize()
+            ms = g.sharding.max_over_ranks(r0.elapsed_time(r1), device=dev)
+            sz = 4 if args.dtype == "f32" else 8
+            per_step = sz * (7 + 3 * N) + 2                                   # action, obs, reward, done, outcome
+            state = sz * (6 + 4 * N) + 12 + sz + sz * (3 + 2 * N) + 4 + sz    # state read + written once per launch
+            b = E * (per_step * T + state)
+            fused = {"value": E * world * T * reps / (ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": T,
+                     "launch_ms": ms / reps, "algorithmic_bytes_per_env_step": per_step + state / T,
+                     "achieved_GBps": b * reps / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": b * reps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "acas2d_rollout: state in registers across steps, actions[t] in, obs/reward/done[t] out; "
+                             "bit-identical to per-step launches"}
+            del out, act
+        except Exception as e:  # noqa: BLE001
+            fused = {"error": str(e)}
+
     if rank == 0:
         s = 4 if args.dtype == "f32" else 8
         bytes_per_launch = E * g.ACAS2DConfig.algorithmic_bytes_per_env_step(N, s)
@@ -187,6 +222,8 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launch_us": launch_us},
         }
+        if fused is not None:
+            out["fused_rollout"] = fused
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(E, N, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...) {
 // G in {1, 4, 16, 64} lanes per env.  Tuned on MI355X.
 Shape choose_shape(int n, int elem_size) {
     const int c16 = 16 / elem_size;                       // values per 16-byte vector
+    if (n == 1) return Shape{1, 1, true};
     if (n == 2) return Shape{2, 1, true};
     if (n == 3) return Shape{3, 1, true};
     if (n % c16 == 0) {
@@ -49,6 +50,14 @@ int acas2d_step_f32(const Acas2dConfig* cfg, const Acas2dState* state, const Aca
 int acas2d_step_f64(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dStepIO* io, uint32_t flags,
                     uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, void* stream) {
     return launch_step<double>(cfg, state, io, flags, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
+}
+int acas2d_rollout_f32(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dStepIO* io, int32_t n_steps,
+                       uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, void* stream) {
+    return launch_rollout<float>(cfg, state, io, n_steps, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
+}
+int acas2d_rollout_f64(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dStepIO* io, int32_t n_steps,
+                       uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, void* stream) {
+    return launch_rollout<double>(cfg, state, io, n_steps, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
 }
 int acas2d_reset_f32(const Acas2dConfig* cfg, const Acas2dState* state, const uint8_t* mask, void* obs,
                      int32_t do_init, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,

@@ -1,11 +1,12 @@
 // float32 instantiation (throughput mode, FAST formulation).  Built with -ffp-contract=fast.
-#define ACAS2D_PACKED_SHAPES(X) X(2, 1) X(3, 1) X(4, 1) X(8, 1) X(4, 2) X(2, 4) X(4, 4) X(4, 8) X(4, 16) X(8, 8) X(2, 32)
+#define ACAS2D_PACKED_SHAPES(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(8, 1) X(4, 2) X(2, 4) X(4, 4) X(4, 8) X(4, 16) X(8, 8) X(2, 32)
 namespace acas2d {
 constexpr bool kFast = true;
 }
 #include "acas2d_launch.inl"
 namespace acas2d {
 template int launch_step<float>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, uint32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
+template int launch_rollout<float>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int launch_reset<float>(const Acas2dConfig*, const Acas2dState*, const uint8_t*, void*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int shape_geometry<float>(int64_t, int32_t, int32_t*, int32_t*, int64_t*);
 }

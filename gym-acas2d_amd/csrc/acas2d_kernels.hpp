@@ -556,7 +556,7 @@ __device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int i0)
 template <typename T, int C, int G, bool PACKED, bool FAST>
 __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
                                            int e, int j, int N, int32_t steps, bool move,
-                                           Traffic<T, C>& tr, T* __restrict__ row) {
+                                           Traffic<T, C>& tr, T* __restrict__ row, bool store_traffic = true) {
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
     Seen<T> r;
     r.d_goal = c.d_goal; r.h_goal = c.h_goal; r.d_dev = c.d_dev;
@@ -580,7 +580,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
         asm volatile("" :: "v"(tr.x.v[0]), "v"(tr.y.v[0]));
         if (false) {
 #else
-        if (move) {
+        if (move && store_traffic) {
 #endif
 #if ACAS2D_OBS_STORE >= 2
             store_chunk<T, C>(reinterpret_cast<V*>(s.trf_x + i0), tr.x);
@@ -742,7 +742,8 @@ template <typename T, bool FAST, int NS>
 __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetParams& rp, const State<T>& s,
                                                const StepIO<T>& io, uint32_t k0, uint32_t k1, uint64_t gid,
                                                int e, int N_dyn, int lane, T total, int32_t steps,
-                                               uint32_t episode_prev, T* __restrict__ row) {
+                                               uint32_t episode_prev, T* __restrict__ row,
+                                               T* __restrict__ scratch = nullptr) {
     const int N = NS > 0 ? NS : N_dyn;                   // compile-time for packed shapes
     const int D = 5 + 3 * N;
 #ifdef ACAS2D_STAMPS
@@ -765,9 +766,14 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
         reset_entity<T>(rp, k0, k1, g_lo, g_hi, episode, lane, tx, ty, tpsi, tv);
         if (lane == 0) {
             psi_own = tpsi;
+            if (scratch) scratch[4 * N] = tpsi;
         } else {
             const int i = e * N + (lane - 1);
             s.trf_x[i] = tx; s.trf_y[i] = ty; s.trf_psi[i] = tpsi; s.trf_v[i] = tv;
+            if (scratch) {                               // rollout: owner lanes pick the state up from LDS
+                const int n = lane - 1;
+                scratch[n] = tx; scratch[N + n] = ty; scratch[2 * N + n] = tpsi; scratch[3 * N + n] = tv;
+            }
         }
     }
     if constexpr (NS == 0 || NS > 63) {
@@ -776,6 +782,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
             reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, ps, v);
             const int i = e * N + n;
             s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = ps; s.trf_v[i] = v;
+            if (scratch) { scratch[n] = x; scratch[N + n] = y; scratch[2 * N + n] = ps; scratch[3 * N + n] = v; }
         }
     }
     ACAS2D_STAMP(9, wave_dbg, lane, false);
@@ -881,12 +888,17 @@ __device__ __forceinline__ T* wave_tile(int tile_elems) {
     return reinterpret_cast<T*>(lds_raw) + (threadIdx.x >> 6) * tile_elems;
 }
 
-// ACAS2DEnv.step(), environment.py:29-42.
-template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST>
+// ACAS2DEnv.step(), environment.py:29-42 -- and, with ROLLOUT, n_steps of them fused in one launch:
+// the state stays in registers, step t reads actions[t][E] and writes obs[t][E][D], reward[t][E],
+// done[t][E], outcome[t][E] (and the optional auto-reset side channels [t][E]...), finished envs
+// are reset on the fly (ROLLOUT implies AUTO_RESET semantics and a packed shape).  The per-step
+// arithmetic is this same code, so rollout(T) == T x step() bit for bit.
+template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT>
 __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetParams rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
-                                                      int tile_elems) {
+                                                      int tile_elems, int n_steps) {
+    static_assert(!ROLLOUT || (AUTO_RESET && PACKED), "rollout: auto-reset semantics, packed shapes");
     const Params<T> p = pinned(p_arg);
     constexpr int NS = PACKED ? C * G : 0;         // packed shapes: n_traffic is a compile-time constant
     const int N = PACKED ? NS : N_arg;
@@ -901,103 +913,136 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
     const int n_rows = (int)((n_envs - e_wave) < EPW ? (n_envs - e_wave) : EPW);
     const bool active = el < n_rows;               // whole groups are active or not
     const State<T> s = rebase(s_arg, e_wave, N);   // everything below indexes envs by `el`
-    const StepIO<T> io = rebase(io_arg, e_wave, D);
+    const StepIO<T> io0 = rebase(io_arg, e_wave, D);
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    // per wave: the observation tile, then (rollout) 4N+1 values of reset hand-off scratch
     T* tile = reinterpret_cast<T*>(lds_raw) + wib * tile_elems;
     T* row = tile + el * D;
+    T* scratch = ROLLOUT ? tile + EPW * D : nullptr;
 
     ACAS2D_STAMP(0, wave, lane, false);
     ACAS2D_STAMP(1, wave, lane, false);
-    uint8_t oc = 0;
     int32_t steps = 0;
     uint32_t episode = 0;
     T total = T(0);
     Own<T> o{};
+    Traffic<T, C> tr{};
+    bool frozen = false;
     if (active) {
         // ---- every load of this lane up front: one memory round trip, all requests in flight ----
-        Traffic<T, C> tr;
         if constexpr (PACKED) tr = load_traffic<T, C>(s, el * N + j * C);
         o = Own<T>{s.own_x[el], s.own_y[el], s.own_psi[el], s.own_v[el], T(0), s.goal_x[el], s.goal_y[el]};
-        const T action = io.actions[el];
         steps = s.steps[el];
         total = s.total_reward[el];
-        bool frozen = false;
         if constexpr (AUTO_RESET) episode = s.episode[el];
         else frozen = s.status[el] != 0;                                   // game.py:243-245
-        ACAS2D_STAMP(2, wave, lane, true);
-
-        // game.py:225 + aircraft.py:16-26 for the player
-        o.a_lat = action * p.acc_lat_limit;
-        if constexpr (FAST) {
-            o.psi = wrap360_window(o.psi + o.a_lat * f_rcp(o.v));   // (a_lat / (v dt)) dt
-            T sn, cs;
-            f_sincos_rev(o.psi * Const<T>::inv360, &sn, &cs);
-            const T vdt = o.v * p.dt;
-            o.x = m_fma(vdt, cs, o.x);
-            o.y = m_fma(vdt, sn, o.y);
-        } else {
-            T psi_dot = o.a_lat / (o.v * p.dt);
-            o.psi = py_mod360(o.psi + (psi_dot * p.dt));
-            T sn, cs;
-            m_sincos(deg2rad_ref(o.psi), &sn, &cs);
-            o.x = o.x + ((o.v * cs) * p.dt);
-            o.y = o.y + ((o.v * sn) * p.dt);
-        }
-        steps += 1;                                                       // game.py:197
-        // `episode` is first USED in the reset loop far below; without this use the compiler waits
-        // for its load there with s_waitcnt vmcnt(0) -- i.e. for every store issued since.
-        asm volatile("" : "+v"(episode));
-        Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row);
-
-        // game.py:249-292 evaluate()
-        T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
-        if constexpr (FAST) rw = rw * (T(1) - (T)steps * p.inv_max_steps);
-        else rw = rw * (T(1) - ((T)steps / (T)p.max_steps));              // :262-263
-        const bool at_goal = r.d_goal < p.goal_radius;                    // :191-192
-        if (r.collided) rw += p.reward_collision;                         // :279-280
-        if (at_goal) rw += p.reward_goal;                                 // :283-284
-        // game.py:294-314 is_done(): timeout > collision > goal
-        oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
-#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 4
-        asm volatile("" :: "v"(rw), "v"(o.x), "v"(o.y), "v"(o.psi));
-        if (false) {
-#else
-        if (j == 0) {
-#endif
-            total = total + rw;                                           // :287
-            io.reward[el] = rw;
-            io.done[el] = oc != 0;
-            io.outcome[el] = oc;
-            if (oc == 0 || !AUTO_RESET) {
-                s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
-                s.steps[el] = steps;
-                s.total_reward[el] = total;
-                if constexpr (!AUTO_RESET) { if (oc) s.status[el] = oc; }
-            }
-        }
     }
 
-    ACAS2D_STAMP(3, wave, lane, false);
-    // Flush the tile now: the stores drain while finished envs (if any) are being reset below.
-    wave_lds_fence();
-    T* const obs_wave = io.obs;
-#if !defined(ACAS2D_ABLATE) || ACAS2D_ABLATE < 2
-    flush_tile<T>(tile, obs_wave, n_rows * D, lane);
+    const int T_steps = ROLLOUT ? n_steps : 1;
+    T action_next = active ? io0.actions[el] : T(0);       // step t+1's action is fetched during step t
+    for (int t = 0; t < T_steps; ++t) {
+        // outputs of step t: [t][E] / [t][E][D] slices (t == 0 for the per-step launch)
+        const int64_t te = ROLLOUT ? (int64_t)t * n_envs : 0;
+        const StepIO<T> io{io0.actions + te, io0.obs + te * D, io0.reward + te, io0.done + te, io0.outcome + te,
+                           io0.term_obs ? io0.term_obs + te * D : nullptr,
+                           io0.ep_return ? io0.ep_return + te : nullptr,
+                           io0.ep_steps ? io0.ep_steps + te : nullptr};
+        const bool last = !ROLLOUT || t == T_steps - 1;
+        uint8_t oc = 0;
+        const T action = action_next;
+        if (ROLLOUT && active && t + 1 < T_steps) action_next = io.actions[n_envs + el];
+        if (active) {
+            if (t == 0) ACAS2D_STAMP(2, wave, lane, true);
+
+            // game.py:225 + aircraft.py:16-26 for the player
+            o.a_lat = action * p.acc_lat_limit;
+            if constexpr (FAST) {
+                o.psi = wrap360_window(o.psi + o.a_lat * f_rcp(o.v));   // (a_lat / (v dt)) dt
+                T sn, cs;
+                f_sincos_rev(o.psi * Const<T>::inv360, &sn, &cs);
+                const T vdt = o.v * p.dt;
+                o.x = m_fma(vdt, cs, o.x);
+                o.y = m_fma(vdt, sn, o.y);
+            } else {
+                T psi_dot = o.a_lat / (o.v * p.dt);
+                o.psi = py_mod360(o.psi + (psi_dot * p.dt));
+                T sn, cs;
+                m_sincos(deg2rad_ref(o.psi), &sn, &cs);
+                o.x = o.x + ((o.v * cs) * p.dt);
+                o.y = o.y + ((o.v * sn) * p.dt);
+            }
+            steps += 1;                                                       // game.py:197
+            // `episode` is first USED in the reset loop far below; without this use the compiler waits
+            // for its load there with s_waitcnt vmcnt(0) -- i.e. for every store issued since.
+            asm volatile("" : "+v"(episode));
+            Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last);
+
+            // game.py:249-292 evaluate()
+            T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
+            if constexpr (FAST) rw = rw * (T(1) - (T)steps * p.inv_max_steps);
+            else rw = rw * (T(1) - ((T)steps / (T)p.max_steps));              // :262-263
+            const bool at_goal = r.d_goal < p.goal_radius;                    // :191-192
+            if (r.collided) rw += p.reward_collision;                         // :279-280
+            if (at_goal) rw += p.reward_goal;                                 // :283-284
+            // game.py:294-314 is_done(): timeout > collision > goal
+            oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
+            total = total + rw;                                               // :287
+#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 4
+            asm volatile("" :: "v"(rw), "v"(o.x), "v"(o.y), "v"(o.psi));
+            if (false) {
+#else
+            if (j == 0) {
 #endif
-    ACAS2D_STAMP(4, wave, lane, false);
-    if constexpr (AUTO_RESET) {
-        // ---- finished envs: one bit per env (its group's lane 0), handled by the whole wave ----
-        unsigned long long dm = __ballot(oc != 0 && j == 0);
-        while (dm) {
-            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);   // wave-uniform
-            dm &= dm - 1;
-            const int el_d = src / G;
-            wave_reset_env<T, FAST, NS>(p, rp, s, io, k0, k1, (uint64_t)(env_offset + e_wave + el_d), el_d, N, lane,
-                                        lane_value(total, src), lane_value(steps, src),
-                                        (uint32_t)lane_value((int)episode, src), tile + el_d * D);
-            wave_lds_fence();                         // the fresh row is complete
-            flush_rows<T>(tile, obs_wave, n_rows * D, el_d * D, (el_d + 1) * D, lane);
+                io.reward[el] = rw;
+                io.done[el] = oc != 0;
+                io.outcome[el] = oc;
+                if (last && (oc == 0 || !AUTO_RESET)) {
+                    s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
+                    s.steps[el] = steps;
+                    s.total_reward[el] = total;
+                    if constexpr (!AUTO_RESET) { if (oc) s.status[el] = oc; }
+                }
+            }
         }
+
+        if (t == 0) ACAS2D_STAMP(3, wave, lane, false);
+        // Flush the tile now: the stores drain while finished envs (if any) are being reset below.
+        wave_lds_fence();
+        T* const obs_wave = io.obs;
+#if !defined(ACAS2D_ABLATE) || ACAS2D_ABLATE < 2
+        flush_tile<T>(tile, obs_wave, n_rows * D, lane);
+#endif
+        if (t == 0) ACAS2D_STAMP(4, wave, lane, false);
+        if constexpr (AUTO_RESET) {
+            // ---- finished envs: one bit per env (its group's lane 0), handled by the whole wave ----
+            unsigned long long dm = __ballot(oc != 0 && j == 0);
+            while (dm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);   // wave-uniform
+                dm &= dm - 1;
+                const int el_d = src / G;
+                wave_reset_env<T, FAST, NS>(p, rp, s, io, k0, k1, (uint64_t)(env_offset + e_wave + el_d), el_d, N, lane,
+                                            lane_value(total, src), lane_value(steps, src),
+                                            (uint32_t)lane_value((int)episode, src), tile + el_d * D, scratch);
+                wave_lds_fence();                         // the fresh row (and scratch) is complete
+                flush_rows<T>(tile, obs_wave, n_rows * D, el_d * D, (el_d + 1) * D, lane);
+                if constexpr (ROLLOUT) {
+                    if (el == el_d) {                     // the owner group continues with the new episode
+#pragma unroll
+                        for (int k = 0; k < C; ++k) {
+                            const int n = j * C + k;
+                            tr.x.v[k] = scratch[n]; tr.y.v[k] = scratch[N + n];
+                            tr.psi.v[k] = scratch[2 * N + n]; tr.v.v[k] = scratch[3 * N + n];
+                        }
+                        o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, scratch[4 * N], (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+                        steps = 1;                                            // environment.py:47
+                        total = T(0);
+                        episode += 1u;
+                    }
+                    wave_lds_fence();                     // scratch is free for the next finished env
+                }
+            }
+        }
+        if constexpr (ROLLOUT) wave_lds_fence();          // tile reads precede the next step's row writes
     }
     ACAS2D_STAMP(5, wave, lane, false);
     ACAS2D_STAMP(6, wave, lane, true);
@@ -1054,6 +1099,9 @@ Shape choose_shape(int n_traffic, int elem_size);
 template <typename T>
 int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, uint32_t flags,
                 uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream);
+template <typename T>
+int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, int32_t n_steps,
+                   uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream);
 template <typename T>
 int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* mask, void* obs,
                  int32_t do_init, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,

@@ -57,12 +57,13 @@ static int check_launch(const char* what) {
 struct Geometry { unsigned grid; int tile_elems; size_t lds_bytes; };
 
 template <typename T>
-static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g) {
+static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g, bool rollout = false) {
     const int64_t epw = 64 / sh.G, envs_per_block = epw * kWavesPerBlock;
     const int64_t blocks = (n_envs + envs_per_block - 1) / envs_per_block;
     if (blocks > 0x7fffffffLL) { set_error("n_envs = %lld exceeds the grid limit", (long long)n_envs); return ACAS2D_EINVAL; }
     const int W = 16 / (int)sizeof(T);
-    const int64_t elems = ((epw * (5 + 3 * (int64_t)n_traffic) + W - 1) / W) * W;
+    const int64_t scratch = rollout ? 4 * (int64_t)n_traffic + 1 : 0;     // reset hand-off, per wave
+    const int64_t elems = ((epw * (5 + 3 * (int64_t)n_traffic) + scratch + W - 1) / W) * W;
     const int64_t bytes = elems * kWavesPerBlock * (int64_t)sizeof(T);
     if (bytes > 64 * 1024) {
         set_error("n_traffic = %d needs a %lld-byte LDS observation tile per workgroup (limit 65536)", n_traffic, (long long)bytes);
@@ -77,11 +78,19 @@ static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, c
                        const ResetParams& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
                        int64_t env_offset, int64_t n_envs, int N) {
     if (auto_reset)
-        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems);
+        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1);
     else
-        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, kFast>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems);
+        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1);
+}
+
+template <typename T, int C, int G>
+static void rollout_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
+                          const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
+                          int64_t n_envs, int N, int n_steps) {
+    hipLaunchKernelGGL((step_kernel<T, C, G, true, true, kFast, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps);
 }
 
 template <typename T, int C, int G, bool PACKED>
@@ -153,6 +162,38 @@ int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStep
         }
     }
     return check_launch("acas2d_step launch");
+}
+
+template <typename T>
+int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_, int32_t n_steps,
+                   uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
+    if (!cfg || !io_) { set_error("acas2d_rollout: NULL cfg / io"); return ACAS2D_EINVAL; }
+    if (!state_complete(st)) { set_error("acas2d_rollout: NULL state or a NULL state buffer"); return ACAS2D_EINVAL; }
+    if (!io_->actions || !io_->obs || !io_->reward || !io_->done || !io_->outcome) {
+        set_error("acas2d_rollout: actions, obs, reward, done and outcome are required"); return ACAS2D_EINVAL; }
+    if (n_traffic < 1 || n_steps < 1) { set_error("acas2d_rollout: n_traffic = %d, n_steps = %d", n_traffic, n_steps); return ACAS2D_EINVAL; }
+    if (n_envs < 0 || env_offset < 0) { set_error("acas2d_rollout: negative n_envs / env_offset"); return ACAS2D_EINVAL; }
+    if (n_envs == 0) return ACAS2D_OK;
+    Shape sh;
+    if (int rc = resolve_shape<T>(n_traffic, &sh)) return rc;
+    if (!sh.packed) {
+        set_error("acas2d_rollout: n_traffic = %d has no packed work shape for this element type "
+                  "(needs n_traffic in {1,2,3} or a multiple of %d tiling a wave); use acas2d_step", n_traffic,
+                  16 / (int)sizeof(T));
+        return ACAS2D_EINVAL;
+    }
+    Geometry g;
+    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g, true)) return rc;
+    const Params<T> p = make_params<T>(*cfg);
+    const ResetParams rp = make_reset_params(*cfg);
+    const State<T> s = make_state<T>(*st);
+    const StepIO<T> io{(const T*)io_->actions, (T*)io_->obs, (T*)io_->reward, io_->done, io_->outcome,
+                       (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#define X(C_, G_) if (sh.C == C_ && sh.G == G_) rollout_shape<T, C_, G_>(g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, n_steps);
+    ACAS2D_PACKED_SHAPES(X)
+#undef X
+    return check_launch("acas2d_rollout launch");
 }
 
 template <typename T>

@@ -25,7 +25,8 @@ class CStepIO(C.Structure):
 
 
 EXPORTS = ("acas2d_abi_version", "acas2d_config_size", "acas2d_last_error", "acas2d_step_f32",
-           "acas2d_step_f64", "acas2d_reset_f32", "acas2d_reset_f64", "acas2d_launch_geometry")
+           "acas2d_step_f64", "acas2d_rollout_f32", "acas2d_rollout_f64", "acas2d_reset_f32",
+           "acas2d_reset_f64", "acas2d_launch_geometry")
 
 
 class NativeLibraryError(RuntimeError):
@@ -70,6 +71,11 @@ def lib():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.POINTER(CStepIO), C.c_uint32,
+                      C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+    for name in ("acas2d_rollout_f32", "acas2d_rollout_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.POINTER(CStepIO), C.c_int32,
                       C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
     for name in ("acas2d_reset_f32", "acas2d_reset_f64"):
         f = getattr(L, name)

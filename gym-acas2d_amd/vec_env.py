@@ -247,6 +247,47 @@ class ACAS2DVecEnv:
                                    self._flags, self.seed_value, self.env_offset, self.num_envs,
                                    self.n_traffic, self._stream()))
 
+    def rollout(self, actions, out=None, keep_terminal_obs=False):
+        """T consecutive step() calls fused into ONE kernel launch (acas2d_rollout_*): the inner loop
+        of a rollout collector when the actions are known up front (scripted / random policies:
+        baseline_main.py:39-61) -- state stays in registers, no kernel boundary between steps.
+
+        actions  [T, E] (or [T, E, 1]) tensor of this env's dtype on its device.
+        Returns a dict of device tensors: obs [T, E, D], reward [T, E], done [T, E] bool,
+        outcome [T, E] uint8, episode_return [T, E], episode_steps [T, E] (the last two, and
+        terminal_observation [T, E, D] if keep_terminal_obs, are written only where done).
+        Bit-identical to T step() calls; VecEnv auto-reset semantics.  Pass the returned dict back
+        as `out` to reuse the buffers."""
+        if not self.auto_reset:
+            raise RuntimeError("rollout() has VecEnv auto-reset semantics; construct with auto_reset=True")
+        a = actions.reshape(actions.shape[0], -1)
+        T, E, D = a.shape[0], self.num_envs, self.obs_dim
+        if a.shape[1] != E or a.dtype != self.dtype or a.device != self.device:
+            raise ValueError("actions must be a [T, %d] %s tensor on %s" % (E, self.dtype, self.device))
+        a = a.contiguous()
+        dev = self.device
+        if out is None:
+            out = {"obs": torch.empty(T, E, D, dtype=self.dtype, device=dev),
+                   "reward": torch.empty(T, E, dtype=self.dtype, device=dev),
+                   "done_u8": torch.empty(T, E, dtype=torch.uint8, device=dev),
+                   "outcome": torch.empty(T, E, dtype=torch.uint8, device=dev),
+                   "episode_return": torch.zeros(T, E, dtype=self.dtype, device=dev),
+                   "episode_steps": torch.zeros(T, E, dtype=torch.int32, device=dev),
+                   "terminal_observation": (torch.zeros(T, E, D, dtype=self.dtype, device=dev)
+                                            if keep_terminal_obs else None)}
+            out["done"] = out["done_u8"].view(torch.bool)
+        assert out["obs"].shape == (T, E, D)
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        io = native.CStepIO(ptr(a), ptr(out["obs"]), ptr(out["reward"]), ptr(out["done_u8"]), ptr(out["outcome"]),
+                            ptr(out.get("terminal_observation")), ptr(out["episode_return"]),
+                            ptr(out["episode_steps"]))
+        fn = self._lib.acas2d_rollout_f32 if self.dtype == torch.float32 else self._lib.acas2d_rollout_f64
+        with torch.cuda.device(dev):
+            native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), T, self.seed_value,
+                            self.env_offset, E, self.n_traffic, self._stream()))
+        out["_actions"] = a          # keep the (possibly re-laid-out) input alive until the launch ran
+        return out
+
     @property
     def actions_buffer(self):
         return self._actions

@@ -134,6 +134,23 @@ int acas2d_step_f64(const Acas2dConfig *cfg, const Acas2dState *state, const Aca
                     int32_t n_traffic, void *stream);
 
 /*
+ * acas2d_rollout_*: n_steps consecutive ACAS2DEnv.step() calls fused into ONE launch -- the inner
+ * loop of a rollout collector (baseline_main.py:39-61 / testing_main.py:69-105 with the actions
+ * known up front; SB3's collect_rollouts once the policy runs on the device).  The state stays in
+ * registers, step t reads actions[t][E] and writes obs[t][E][D], reward[t][E], done[t][E],
+ * outcome[t][E]; term_obs [t][E][D], ep_return [t][E], ep_steps [t][E] are optional (NULL) and
+ * written only where done[t][e].  ACAS2D_AUTO_RESET semantics always.  Bit-identical to n_steps
+ * acas2d_step_* calls.  Needs a packed work shape: n_traffic in {1, 2, 3} or a multiple of
+ * 16 / sizeof(T) that tiles a wave (4, 8, 16, 32, 64 for f32), else ACAS2D_EINVAL.
+ */
+int acas2d_rollout_f32(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
+                       int32_t n_steps, uint64_t seed, int64_t env_offset, int64_t n_envs,
+                       int32_t n_traffic, void *stream);
+int acas2d_rollout_f64(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
+                       int32_t n_steps, uint64_t seed, int64_t env_offset, int64_t n_envs,
+                       int32_t n_traffic, void *stream);
+
+/*
  * acas2d_reset_*: replaces ACAS2DEnv.reset() (environment.py:44-48 -> ACAS2DGame.__init__,
  * game.py:28-41,80-116, then observe()).  For every env with mask[e] != 0 (mask == NULL: all):
  *   do_init != 0: draw a fresh episode from the Philox stream described above

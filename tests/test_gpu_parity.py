@@ -324,6 +324,47 @@ def test_f32_reset_names_the_same_episodes(g, O):
     assert checked > 50
 
 
+@pytest.mark.parametrize("dtype_name,N,E,T", (("float32", 8, 4096, 160), ("float64", 8, 1024, 120), ("float32", 64, 512, 40),
+                                               ("float32", 3, 2048, 60), ("float32", 1, 640, 450), ("float64", 3, 333, 50)))
+def test_rollout_equals_sequential_steps(g, dtype_name, N, E, T):
+    """acas2d_rollout_* (T steps fused in one launch, state in registers) == T x acas2d_step_*,
+    bit for bit: observations, rewards, masks, side channels and the final state."""
+    dtype = getattr(torch, dtype_name)
+    dev = "cuda:0"
+    a = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=77, env_offset=5)
+    b = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=77, env_offset=5)
+    a.reset()
+    b.reset()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    actions = torch.rand(T, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
+    out = a.rollout(actions, keep_terminal_obs=True)
+    torch.cuda.synchronize()
+    dones = 0
+    for t in range(T):
+        obs, rew, done, infos = b.step(actions[t])
+        assert torch.equal(out["obs"][t], obs), t
+        assert torch.equal(out["reward"][t], rew) and torch.equal(out["done"][t], done)
+        assert torch.equal(out["outcome"][t], infos.outcome)
+        d = done
+        if bool(d.any()):
+            dones += int(d.sum())
+            assert torch.equal(out["episode_return"][t][d], infos.episode_return[d])
+            assert torch.equal(out["episode_steps"][t][d], infos.episode_steps[d])
+            assert torch.equal(out["terminal_observation"][t][d], infos.terminal_observation[d])
+    assert dones > 0
+    for name in ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi", "trf_v",
+                 "steps", "total_reward", "episode"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    # and a second rollout continues from the state the first one left, reusing the buffers
+    actions2 = torch.rand(T, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
+    out = a.rollout(actions2, out=out)
+    for t in range(T):
+        obs, rew, done, _ = b.step(actions2[t])
+        assert torch.equal(out["obs"][t], obs) and torch.equal(out["done"][t], done)
+    with pytest.raises(RuntimeError, match="packed work shape"):
+        g.ACAS2DVecEnv(16, 5, device=dev, dtype=dtype).rollout(torch.zeros(2, 16, device=dev, dtype=dtype))
+
+
 def test_lazy_infos_and_vecenv_surface(g):
     E, N = 256, 64                          # N = 64: episodes last ~8 steps -> many dones
     env = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, seed=3)

@@ -68,8 +68,8 @@ def test_parity_reset_reproduces_reference_draws(g):
 def test_c_abi_library_loads_and_exports_every_declared_symbol(g):
     header = open(os.path.join(ROOT, "include", "acas2d.h")).read()
     declared = set(re.findall(r"\b(acas2d_[a-z0-9_]+)\s*\(", header))
-    assert {"acas2d_step_f32", "acas2d_step_f64", "acas2d_reset_f32", "acas2d_reset_f64",
-            "acas2d_last_error", "acas2d_abi_version"} <= declared
+    assert {"acas2d_step_f32", "acas2d_step_f64", "acas2d_rollout_f32", "acas2d_rollout_f64",
+            "acas2d_reset_f32", "acas2d_reset_f64", "acas2d_last_error", "acas2d_abi_version"} <= declared
     L = g.native.lib()
     for name in declared:
         assert hasattr(L, name), name

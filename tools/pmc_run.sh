@@ -4,7 +4,7 @@
 tag=$1; counters=$2; shift 2
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $counters --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 20 --launch eager --no-cpu-baseline "$@" > $out.log 2>&1
+rocprofv3 --pmc $counters --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 20 --launch eager --no-cpu-baseline --no-rollout "$@" > $out.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 files = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)

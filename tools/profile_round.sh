@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 2000 --warmup 200 > $O/bench_traced.json 2> $O/bench_traced.err
 for E in 65536 4194304; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $O/pmc_${c}_$E -- python3 $R/bench.py --envs $E --steps 40 --warmup 10 --launch eager --no-cpu-baseline > $O/pmc_${c}_$E.json 2> $O/pmc_${c}_$E.err
+    rocprofv3 --pmc $c --output-format csv -d $O/pmc_${c}_$E -- python3 $R/bench.py --envs $E --steps 40 --warmup 10 --launch eager --no-cpu-baseline --no-rollout > $O/pmc_${c}_$E.json 2> $O/pmc_${c}_$E.err
   done
 done
 python3 $R/bench.py --steps 2000 --warmup 200 > $O/bench_plain.json 2> $O/bench_plain.err

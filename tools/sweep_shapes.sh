@@ -5,7 +5,7 @@ envs=$1; traffic=$2; dtype=$3; out=$4; shift 4
 for sh in "$@"; do
   echo "== shape $sh envs=$envs N=$traffic $dtype $EXTRA" >> "$out"
   ACAS2D_SHAPE="$sh" timeout -k 10 120 python bench.py --envs "$envs" --traffic "$traffic" --dtype "$dtype" \
-      --steps ${STEPS:-1000} --warmup 100 --no-cpu-baseline $EXTRA 2>&1 | python -c "
+      --steps ${STEPS:-1000} --warmup 100 --no-cpu-baseline --no-rollout $EXTRA 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
