@@ -37,7 +37,10 @@
 
 namespace acas2d {
 
-constexpr int kBlock = 256;
+#ifndef ACAS2D_BLOCK
+#define ACAS2D_BLOCK 256
+#endif
+constexpr int kBlock = ACAS2D_BLOCK;      // threads per workgroup (tuning knob; 256 measured best)
 constexpr int kWavesPerBlock = kBlock / 64;
 
 // In-kernel stamps: DIAGNOSTIC build only (tools/diag_stamps.py builds libacas2d_hip_diag.so with
