@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libacas2d_oracle.so")
+# ACAS2D_ORACLE_LIB: load another build of the oracle (e.g. the -fsanitize=address,undefined one)
+_LIB_PATH = os.environ.get("ACAS2D_ORACLE_LIB") or os.path.join(_HERE, "_build", "libacas2d_oracle.so")
 
 G0 = 9.80665  # scipy.constants.g (settings.py:1)
 
@@ -73,6 +74,8 @@ def default_config():
 
 
 def build(force=False):
+    if os.environ.get("ACAS2D_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "acas2d_oracle.c")):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
