@@ -160,7 +160,7 @@ class PPOTrainer:
                 loss.backward()
                 nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
                 self.opt.step()
-            stats = {"pg_loss": float(pg), "value_loss": float(vf), "std": float(self.policy.log_std.exp())}
+            stats = {"pg_loss": pg.item(), "value_loss": vf.item(), "std": self.policy.log_std.detach().exp().item()}
         return stats
 
     def recent_episodes(self, clear=True):
