@@ -102,8 +102,9 @@ class ACAS2DEnv:
         self.game = GameView(self)
         self.game.episode = episode
         if self.record_paths:
-            self.game.path.append((own[0], own[1]))
-            self.game.traffic_paths = [[(t[0], t[1])] for t in trf]
+            # plain Python floats: the reference's CSVs are read back with ast.literal_eval
+            self.game.path.append((float(own[0]), float(own[1])))
+            self.game.traffic_paths = [[(float(t[0]), float(t[1]))] for t in trf]
         self._last_trf = trf[:, :2].copy()
         return obs
 

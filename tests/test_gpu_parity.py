@@ -176,6 +176,33 @@ def test_single_env_adapter_reference_surface(g):
     assert (env.game.traffic[0].x, env.game.traffic[0].y) == t_before
 
 
+def test_records_in_the_reference_csv_layout(g, tmp_path):
+    """baseline_main.simulate() on the adapter: same columns as the reference's CSV, and the first
+    episodes agree with it (outcome, steps, return, path)."""
+    import csv
+    import random
+    dg = H.load("csv_baseline_digest.npz")
+    random.seed(13)
+    env = g.ACAS2DEnv()
+    env.reset()                                  # the game check_env consumed (baseline_main.py:22)
+    cols = g.records.simulate(env, episodes=3)
+    assert tuple(cols) == g.records.BASELINE_COLUMNS and cols["Episode"] == [1, 2, 3]
+    for i in range(3):
+        assert cols["Outcome"][i] == {1: "Goal", 2: "Collision", 3: "Timeout"}[int(dg["outcome"][i])]
+        assert cols["Time Steps"][i] == dg["steps"][i] and len(cols["Path"][i]) == dg["n_points"][i]
+        assert abs(cols["Total Reward"][i] - dg["total_reward"][i]) < 1e-8
+        np.testing.assert_allclose(cols["Path"][i][:2], dg["own_first2"][i], atol=1e-9)
+        np.testing.assert_allclose(cols["Path"][i][-1], dg["own_last"][i], atol=1e-9)
+        np.testing.assert_allclose(cols["Traffic Paths"][i][0][:3], dg["trf_first3"][i], atol=1e-9)
+    out = tmp_path / "baseline.csv"
+    g.records.to_csv(cols, out)
+    rows = list(csv.DictReader(open(out)))
+    assert list(rows[0]) == list(g.records.BASELINE_COLUMNS) and rows[0]["Outcome"] == "Collision"
+    import ast
+    assert rows[0]["Path"].startswith("[(48.0, 500.0), (49.99846871604")      # the reference's file: "[(48, 500.0), (49.998468716044925, ..."
+    assert len(ast.literal_eval(rows[0]["Path"])) == 390 and len(ast.literal_eval(rows[0]["Traffic Paths"])[0]) == 390
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N", (1, 3, 8, 64))
 def test_f32_single_step_vs_f64_oracle(g, O, N):
