@@ -25,7 +25,7 @@ def counter(name, E):
     vals = []
     for f in glob.glob(os.path.join(d, "pmc_%s_%d" % (name, E), "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "step_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            if "step_kernel" in r["Kernel_Name"] and "true, false>" in r["Kernel_Name"] and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"]))
     vals = vals[len(vals) // 4:]
     return statistics.mean(vals) if vals else None
@@ -40,9 +40,12 @@ def alg_bytes(E):
 out = {"dir": os.path.basename(d)}
 ks = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if ks:
-    for r in csv.DictReader(open(ks[0])):
-        if "step_kernel" in r["Name"]:
-            out["kernel_trace"] = {k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")}
+    rows = [r for r in csv.DictReader(open(ks[0])) if "step_kernel" in r["Name"]]
+    rows.sort(key=lambda r: -int(r["Calls"]))          # per-step launches first, then the fused-rollout ones
+    if rows:
+        out["kernel_trace"] = {k: rows[0][k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")}
+    if len(rows) > 1:
+        out["kernel_trace_rollout"] = {k: rows[1][k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")}
 for name in ("bench_traced", "bench_plain"):
     try:
         line = [l for l in open(os.path.join(d, name + ".json")) if l.startswith("{")][-1]
