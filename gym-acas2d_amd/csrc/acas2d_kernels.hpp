@@ -373,8 +373,6 @@ struct alignas((C * sizeof(T)) % 16 == 0 ? 16 : ((C * sizeof(T)) % 8 == 0 ? 8 : 
 
 template <typename T, int W>
 __device__ __forceinline__ void store_chunk(Vec<T, W>* dst, const Vec<T, W>& v);
-template <typename T, int W>
-__device__ __forceinline__ void store_chunk_nt_any(Vec<T, W>* dst, const Vec<T, W>& v);
 
 // ---- one env's player, as every lane of its group sees it ------------------------------------------
 template <typename T>
@@ -587,7 +585,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
 #endif
 #if ACAS2D_OBS_STORE >= 2
             store_chunk<T, C>(reinterpret_cast<V*>(s.trf_x + i0), tr.x);
-            store_chunk_nt_any<T, C>(reinterpret_cast<V*>(s.trf_y + i0), tr.y);
+            store_chunk<T, C>(reinterpret_cast<V*>(s.trf_y + i0), tr.y);
 #else
             *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
             *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
@@ -693,7 +691,7 @@ __device__ __forceinline__ Own<T> reset_env(const ResetParams& rp, const State<T
 
 // Entity `ent` of a fresh episode from ONE Philox block: ent 0 = the player (only its heading is
 // random, returned in opsi; game.py:85-92), ent n + 1 = traffic n (game.py:96-116).  Bitwise the
-// same draws as reset_own_psi() / reset_traffic().
+// same draws as reset_env() / reset_traffic().
 template <typename T>
 __device__ __forceinline__ void reset_entity(const ResetParams& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
                                              uint32_t g_hi, uint32_t episode, int ent, T& ox, T& oy, T& opsi,
@@ -724,15 +722,6 @@ __device__ __forceinline__ void reset_entity(const ResetParams& rp, uint32_t k0,
     const double y = first ? (rp.t0_y_base + (down * rp.t0_y_span)) : uniform(0.0, rp.tn_y_max, u01(w.y));
     const double v = uniform(rp.speed_factor_min, rp.speed_factor_max, u01(w.w)) * rp.airspeed;
     ox = (T)x; oy = (T)y; opsi = (T)psi; ov = (T)v;
-}
-
-// Player draw of a fresh episode (entity 0 of the env's Philox stream), game.py:85-92.
-template <typename T>
-__device__ __forceinline__ T reset_own_psi(const ResetParams& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
-                                           uint32_t g_hi, uint32_t episode) {
-#pragma clang fp contract(off)
-    const U4 w = philox4x32_10(U4{g_lo, g_hi, episode, 0u}, k0, k1);
-    return (T)py_mod360(rp.own_heading0 + uniform(-rp.own_heading_jitter, rp.own_heading_jitter, u01(w.z)));
 }
 
 // Wave-cooperative reset of ONE finished env inside the step kernel (SB3 DummyVecEnv.step_wait
@@ -846,9 +835,6 @@ __device__ __forceinline__ void store_chunk(Vec<T, W>* dst, const Vec<T, W>& v) 
 #endif
 }
 
-template <typename T, int W>
-__device__ __forceinline__ void store_chunk_nt_any(Vec<T, W>* dst, const Vec<T, W>& v) { store_chunk<T, W>(dst, v); }
-
 template <typename T>
 __device__ __forceinline__ void flush_tile(const T* __restrict__ tile, T* __restrict__ dst, int count,
                                            int lane) {
@@ -884,13 +870,6 @@ __device__ __forceinline__ void flush_rows(const T* __restrict__ tile, T* __rest
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------
-// Dynamic LDS: kWavesPerBlock tiles of (64 / G) * D values, 16-byte aligned.
-template <typename T>
-__device__ __forceinline__ T* wave_tile(int tile_elems) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    return reinterpret_cast<T*>(lds_raw) + (threadIdx.x >> 6) * tile_elems;
-}
-
 // ACAS2DEnv.step(), environment.py:29-42 -- and, with ROLLOUT, n_steps of them fused in one launch:
 // the state stays in registers, step t reads actions[t][E] and writes obs[t][E][D], reward[t][E],
 // done[t][E], outcome[t][E] (and the optional auto-reset side channels [t][E]...), finished envs
