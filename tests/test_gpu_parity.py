@@ -319,6 +319,97 @@ def test_f64_auto_reset_vs_oracle(g, O, N, E, T):
     assert dones > 0
 
 
+def _oracle_config_from(O, cfg):
+    """OracleConfig carrying a NON-default product configuration (same field names)."""
+    cc, oc = cfg.to_c(), O.OracleConfig()
+    for name, _ in O.OracleConfig._fields_:
+        setattr(oc, name, getattr(cc, name))
+    return oc
+
+
+@pytest.mark.parametrize("N,E,T", ((2, 1500, 80), (5, 777, 90), (6, 1024, 60), (7, 333, 60), (12, 640, 50), (33, 200, 30)))
+def test_f64_odd_traffic_counts_and_nondefault_config_vs_oracle(g, O, N, E, T):
+    """Generic work shapes (N not a power-of-two multiple of the vector width) and a configuration
+    in which every tunable differs from settings.py -- different airspace, frame rate, radii,
+    reward constants, an airspeed-factor RANGE (so traffic and player speeds differ and the
+    kinematics.py:74 quirk matters everywhere), short episodes (timeouts occur)."""
+    cfg = g.ACAS2DConfig(n_traffic=N, max_steps=120, width=2000, height=1200, fps=50, aircraft_size=20,
+                         airspeed=180, airspeed_factor_min=0.8, airspeed_factor_max=1.3,
+                         acc_lat_limit=150.0, player_initial_heading_lim=10, traffic_initial_heading_lim=25,
+                         reward_goal=500, reward_collision=-750)
+    ref = O.OracleEnvs(E, N, seed=3, env_offset=17, auto_reset=True, config=_oracle_config_from(O, cfg))
+    env = GpuEngine.__new__(GpuEngine)
+    env.v = g.ACAS2DVecEnv(E, device="cuda:0", dtype=torch.float64, seed=3, env_offset=17, config=cfg)
+    env.E, env.N = E, N
+    o1, o2 = ref.reset(), env.reset()
+    for name in ("own_psi", "trf_x", "trf_y", "trf_psi", "trf_v", "goal_x", "own_x"):
+        assert np.array_equal(getattr(env, name), getattr(ref, name)), name
+    assert len(np.unique(ref.trf_v)) > 10                      # speeds really vary
+    np.testing.assert_allclose(o2, o1, rtol=0, atol=1e-9)
+    rng = np.random.default_rng(9)
+    seen = set()
+    for _ in range(T):
+        a = rng.uniform(-1, 1, E)
+        o1, r1, d1, oc1, _ = ref.step(a)
+        o2, r2, d2, oc2, _ = env.step(a)
+        assert np.array_equal(d1, d2) and np.array_equal(oc1, oc2)
+        np.testing.assert_allclose(o2, o1, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(r2, r1, rtol=0, atol=1e-9)
+        seen |= set(np.unique(oc1))
+    assert np.array_equal(env.steps, ref.steps) and np.array_equal(env.episode, ref.episode)
+    assert {0, 2} <= seen
+
+
+def test_f32_statistical_single_step_vs_f64_oracle(g, O):
+    """200 000 mid-episode states (oracle rollouts with resets, N = 8), ONE float32 step each from
+    the identical float32-representable state, against the float64 oracle: the distribution of the
+    observation error, not just a maximum over a few fixtures."""
+    E, N = 200_000, 8
+    ref = O.OracleEnvs(E, N, seed=1234, auto_reset=True)
+    ref.reset()
+    rng = np.random.default_rng(4)
+    for _ in range(int(rng.integers(20, 40))):
+        ref.step(rng.uniform(-1, 1, E))
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)  # noqa: E731
+    own = f32(np.stack([ref.own_x, ref.own_y, ref.own_psi, ref.own_v], 1))
+    trf = f32(np.stack([ref.trf_x, ref.trf_y, ref.trf_psi, ref.trf_v], -1))
+    steps = ref.steps.copy()
+    act = f32(rng.uniform(-1, 1, E))
+    chk = O.OracleEnvs(E, N)
+    chk.set_state(own, trf, None, steps)
+    o, r, d, oc, _ = chk.step(act)
+    env = GpuEngine(g, E, N, dtype=torch.float32)
+    env.set_state(own, trf, None, steps)
+    obs, rew, done, outcome, _ = env.step(act)
+    cfgc = O.default_config()
+    ok = ~grazing(o, N, cfgc, 1e-3)
+    assert ok.mean() > 0.999
+    assert np.array_equal(done[ok], d[ok]) and np.array_equal(outcome[ok], oc[ok])
+    rad = np.deg2rad
+    v12x = (chk.own_v * np.cos(rad(chk.own_psi)))[:, None] - chk.trf_v * np.cos(rad(chk.trf_psi))
+    v12y = (chk.own_v * np.sin(rad(chk.own_psi)))[:, None] - chk.trf_v * np.sin(rad(chk.trf_psi))
+    well = (np.abs(v12x) > 0.02) & (np.hypot(v12x, v12y) > 2.0)
+    err = np.abs(obs - o)
+    err[:, [1, 4]] = np.minimum(err[:, [1, 4]], 1.0 - err[:, [1, 4]])      # headings live on a circle
+    col = np.arange(o.shape[1])
+    cpa = (col >= 5) & ((col - 5) % 3 == 1)
+    e_rest, e_cpa = err[:, ~cpa], err[:, cpa][well]
+    print("f32 one-step |obs error| vs f64 oracle over %d states: non-d_cpa max %.2e p99.9 %.2e; d_cpa (well-conditioned, "
+          "%.2f %% of entries) max %.2e p99.9 %.2e" % (E, e_rest.max(), np.quantile(e_rest, 0.999), 100 * well.mean(),
+                                                       e_cpa.max(), np.quantile(e_cpa, 0.999)))
+    assert e_rest.max() < 1e-5 and e_cpa.max() < 2e-5
+    assert np.quantile(e_rest, 0.999) < 2e-6
+    # the shaped reward multiplies in (d_cpa / 192)^4 (rewards.py:12-16), i.e. it amplifies the
+    # d_cpa entry's error by up to 4 * 1886 / 192 = 39x: 1e-5 holds for 99.99 % of the states,
+    # the worst of 200 000 stays below 5e-5
+    nt = ok & ~d.astype(bool) & well[:, 0]
+    e_rew = np.abs(rew[nt] - r[nt])
+    print("f32 one-step |reward error| (non-terminal): max %.2e p99.99 %.2e" % (e_rew.max(), np.quantile(e_rew, 0.9999)))
+    assert np.quantile(e_rew, 0.9999) < 1e-5 and e_rew.max() < 5e-5
+    assert max(np.abs(env.own_x - chk.own_x).max(), np.abs(env.trf_x - chk.trf_x).max(),
+               np.abs(env.trf_y - chk.trf_y).max()) <= 1.3e-4
+
+
 def test_f32_reset_names_the_same_episodes(g, O):
     """Same seed -> same episodes in both modes.  reset() (reset_kernel) evaluates the draws in
     float64 and rounds once: bit-equal to the rounded oracle.  The in-step auto-reset of the
