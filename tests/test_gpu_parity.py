@@ -393,12 +393,22 @@ def test_f32_statistical_single_step_vs_f64_oracle(g, O):
     err[:, [1, 4]] = np.minimum(err[:, [1, 4]], 1.0 - err[:, [1, 4]])      # headings live on a circle
     col = np.arange(o.shape[1])
     cpa = (col >= 5) & ((col - 5) % 3 == 1)
-    e_rest, e_cpa = err[:, ~cpa], err[:, cpa][well]
-    print("f32 one-step |obs error| vs f64 oracle over %d states: non-d_cpa max %.2e p99.9 %.2e; d_cpa (well-conditioned, "
-          "%.2f %% of entries) max %.2e p99.9 %.2e" % (E, e_rest.max(), np.quantile(e_rest, 0.999), 100 * well.mean(),
-                                                       e_cpa.max(), np.quantile(e_cpa, 0.999)))
-    assert e_rest.max() < 1e-5 and e_cpa.max() < 2e-5
-    assert np.quantile(e_rest, 0.999) < 2e-6
+    vcl = (col >= 5) & ((col - 5) % 3 == 2)
+    # closing speed = dot(dv, dp) / |dp| / dt (kinematics.py:77): for aircraft a few pixels apart
+    # (random spawns on top of the player) float32 position rounding (1.2e-4 px) is a visible
+    # fraction of |dp| -- ill-conditioned in the reference itself; entries with |dp| < 16 px are
+    # bounded separately
+    near = (o[:, 5::3] * cfgc.d_sep_max) < 16.0
+    e_own, e_dist = err[:, :5], err[:, (col >= 5) & ((col - 5) % 3 == 0)]
+    e_vc, e_vc_near, e_cpa = err[:, vcl][~near], err[:, vcl][near], err[:, cpa][well]
+    print("f32 one-step |obs error| vs f64 oracle over %d states: player entries max %.2e; distance max %.2e; closing "
+          "speed max %.2e p99.9 %.2e (|dp| >= 16 px; %d entries closer: max %.2e); d_cpa (well-conditioned, %.2f %%) "
+          "max %.2e p99.9 %.2e" % (E, e_own.max(), e_dist.max(), e_vc.max(), np.quantile(e_vc, 0.999), near.sum(),
+                                   e_vc_near.max() if near.any() else 0.0, 100 * well.mean(), e_cpa.max(),
+                                   np.quantile(e_cpa, 0.999)))
+    assert e_own.max() < 1e-5 and e_dist.max() < 1e-5 and e_vc.max() < 1e-5 and e_cpa.max() < 2e-5
+    assert near.mean() < 1e-3 and (not near.any() or e_vc_near.max() < 1e-3)
+    assert np.quantile(err[:, ~cpa], 0.999) < 2e-6
     # the shaped reward multiplies in (d_cpa / 192)^4 (rewards.py:12-16), i.e. it amplifies the
     # d_cpa entry's error by up to 4 * 1886 / 192 = 39x: 1e-5 holds for 99.99 % of the states,
     # the worst of 200 000 stays below 5e-5
