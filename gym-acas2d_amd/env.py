@@ -118,14 +118,19 @@ class ACAS2DEnv:
         """environment.py:29-42 (without the pygame clock throttle of :31)."""
         a = np.asarray(action, dtype=np.float64).reshape(-1)[:1]
         obs, reward, done, _ = self._vec.step(a)
+        v = self._vec
+        # ONE device -> host transfer per step: obs, reward, done and (for the records) the positions
+        parts = [obs[0], reward[:1], done[:1].to(obs.dtype)]
         if self.record_paths:
-            v = self._vec
-            self.game.path.append((v.own_x[0].item(), v.own_y[0].item()))
-            for n, lst in enumerate(self.game.traffic_paths):
+            parts += [v.own_x[:1], v.own_y[:1], v.trf_x[0], v.trf_y[0]]
+        host = torch.cat(parts).cpu().numpy()
+        D, N = self.config.obs_dim, self.config.n_traffic
+        if self.record_paths:
+            self.game.path.append((float(host[D + 2]), float(host[D + 3])))
+            for n, lst in enumerate(self.game.traffic_paths):       # logged BEFORE the traffic moved
                 lst.append((float(self._last_trf[n, 0]), float(self._last_trf[n, 1])))
-            self._last_trf = np.stack([v.trf_x[0].cpu().numpy(), v.trf_y[0].cpu().numpy()], axis=1)
-        return (obs[0].cpu().numpy().astype(np.float64), float(reward[0].item()),
-                bool(done[0].item()), {})
+            self._last_trf = np.stack([host[D + 4:D + 4 + N], host[D + 4 + N:D + 4 + 2 * N]], axis=1)
+        return host[:D].astype(np.float64), float(host[D]), bool(host[D + 1] != 0), {}
 
     def render(self, mode="human"):
         """The pygame HUD (game.py:316-431) is split out of the GPU path; no-op here."""
