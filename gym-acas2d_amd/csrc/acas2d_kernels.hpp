@@ -375,6 +375,19 @@ template <typename T, int W>
 __device__ __forceinline__ void store_chunk(Vec<T, W>* dst, const Vec<T, W>& v);
 
 // ---- one env's player, as every lane of its group sees it ------------------------------------------
+// A product rounded to T that the compiler can no longer contract into an fma (hipcc's default
+// -ffp-contract=fast lets the backend fuse across statements, whatever a pragma says; an empty asm
+// is the one thing it cannot see through).  The reference's differences of such products --
+// relative velocity v1 cos(psi1) - v2 cos(psi2) (kinematics.py:35-36), the velocity difference of
+// the closing speed (:70-76) -- cancel to EXACTLY 0 in parallel flight: 0/0 -> NaN d_cpa, closing
+// speed 0 -> the `v_closing <= 0` reward branch.  An fma keeps one product unrounded and leaves a
+// ~1e-6 residual that flips both (found by test_f32_reproduces_the_reference_nan_pattern).
+template <typename T>
+__device__ __forceinline__ T rounded(T x) {
+    asm("" : "+v"(x));
+    return x;
+}
+
 template <typename T>
 struct Own {
     T x, y, psi, v, a_lat, gx, gy;
@@ -411,7 +424,7 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
         T s1, c1;
         f_sincos_rev(psi1 * Const<T>::inv360, &s1, &c1);
         const T vdt = o.v * p.dt;
-        c.v1x = vdt * c1; c.v1y = vdt * s1;
+        c.v1x = rounded(vdt * c1); c.v1y = rounded(vdt * s1);
         c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
         const T gdx = o.gx - o.x, gdy = o.gy - o.y;
         c.d_goal = f_sqrt(m_fma(gdy, gdy, gdx * gdx));
@@ -431,6 +444,7 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
     }
     return c;
 }
+
 
 // One traffic aircraft, part 1 -- the traffic half of game.py:222-247 action(): wrap the heading,
 // sin / cos of it, Euler step when `move`.  In/out: tx, ty (moved), tpsi (wrapped); out: st, ct.
@@ -463,17 +477,17 @@ __device__ __forceinline__ void traffic_observe(const Params<T>& p, const OwnCtx
 #endif
     if constexpr (FAST) {
         const T tvdt = tv * p.dt;
-        const T v2x = tvdt * ct, v2yt = tvdt * st;
+        const T v2x = rounded(tvdt * ct), v2yt = tvdt * st;
         const T dx = tx - c.x, dy = ty - c.y;
         d = f_sqrt(m_fma(dy, dy, dx * dx));
         // kinematics.py:40-49: d sin(a_rel - arctan(v12y / v12x))
         //   == sign(v12x) (dy v12x - dx v12y) / |v12|   (sign bit of v12x, so -0.0 counts as
         //   negative like the quotient's; v12 == 0 gives 0 * inf = NaN like the reference's 0/0)
-        const T v12x = m_fma(c.v, c.co, -(tv * ct)), v12y = m_fma(c.v, c.so, -(tv * st));
+        const T v12x = rounded(c.v * c.co) - rounded(tv * ct), v12y = rounded(c.v * c.so) - rounded(tv * st);
         const T cross = m_fma(dy, v12x, -(dx * v12y));
         dca = (m_copysign(T(1), v12x) * cross) * f_rsq(m_fma(v12y, v12y, v12x * v12x));
         // kinematics.py:52-79; v2.y uses the PLAYER's airspeed (:74), kept
-        const T v2y = (c.v * p.dt) * st;
+        const T v2y = rounded((c.v * p.dt) * st);
         const T x2 = tx + v2x, y2 = ty + v2yt;
         const T ax = c.v1x - v2x, ay = c.v1y - v2y, bx = c.x1 - x2, by = c.y1 - y2;
         vc = (m_fma(ay, by, ax * bx) * f_rsq(m_fma(by, by, bx * bx))) * p.inv_dt;
