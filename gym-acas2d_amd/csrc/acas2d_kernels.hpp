@@ -744,12 +744,17 @@ __device__ __forceinline__ void reset_entity(const ResetParams& rp, uint32_t k0,
 // wave); instead all 64 lanes of the wave take one ENTITY each -- lane 0 the player, lane n the
 // traffic aircraft n-1 (strided by 64 beyond that) -- so the new episode costs one Philox block
 // and one traffic_step() of latency.  Must be called by the whole wave (wave-uniform arguments).
-template <typename T, bool FAST, int NS>
+//
+// HANDOFF (packed shapes): the new state goes to the wave's LDS `scratch` (x[N] y[N] psi[N] v[N]
+// own_psi) and nothing but term_obs is stored to memory here -- the owner lanes pick the state up
+// and it leaves with the wave's ordinary, coalesced state stores and its single tile flush.  Without
+// it (generic walk) the entity lanes store the new state themselves and the caller re-flushes the row.
+template <typename T, bool FAST, int NS, bool HANDOFF>
 __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetParams& rp, const State<T>& s,
                                                const StepIO<T>& io, uint32_t k0, uint32_t k1, uint64_t gid,
                                                int e, int N_dyn, int lane, T total, int32_t steps,
                                                uint32_t episode_prev, T* __restrict__ row,
-                                               T* __restrict__ scratch = nullptr) {
+                                               T* __restrict__ scratch) {
     const int N = NS > 0 ? NS : N_dyn;                   // compile-time for packed shapes
     const int D = 5 + 3 * N;
 #ifdef ACAS2D_STAMPS
@@ -772,23 +777,25 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
         reset_entity<T>(rp, k0, k1, g_lo, g_hi, episode, lane, tx, ty, tpsi, tv);
         if (lane == 0) {
             psi_own = tpsi;
-            if (scratch) scratch[4 * N] = tpsi;
+            if constexpr (HANDOFF) scratch[4 * N] = tpsi;
+        } else if constexpr (HANDOFF) {                  // owner lanes pick the state up from LDS
+            const int n = lane - 1;
+            scratch[n] = tx; scratch[N + n] = ty; scratch[2 * N + n] = tpsi; scratch[3 * N + n] = tv;
         } else {
             const int i = e * N + (lane - 1);
             s.trf_x[i] = tx; s.trf_y[i] = ty; s.trf_psi[i] = tpsi; s.trf_v[i] = tv;
-            if (scratch) {                               // rollout: owner lanes pick the state up from LDS
-                const int n = lane - 1;
-                scratch[n] = tx; scratch[N + n] = ty; scratch[2 * N + n] = tpsi; scratch[3 * N + n] = tv;
-            }
         }
     }
     if constexpr (NS == 0 || NS > 63) {
         for (int n = lane + 63; n < N; n += 64) {        // N > 63 only
             T x, y, ps, v;
             reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, ps, v);
-            const int i = e * N + n;
-            s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = ps; s.trf_v[i] = v;
-            if (scratch) { scratch[n] = x; scratch[N + n] = y; scratch[2 * N + n] = ps; scratch[3 * N + n] = v; }
+            if constexpr (HANDOFF) {
+                scratch[n] = x; scratch[N + n] = y; scratch[2 * N + n] = ps; scratch[3 * N + n] = v;
+            } else {
+                const int i = e * N + n;
+                s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = ps; s.trf_v[i] = v;
+            }
         }
     }
     ACAS2D_STAMP(9, wave_dbg, lane, false);
@@ -805,21 +812,24 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
     }
     if constexpr (NS == 0 || NS > 63) {
         for (int n = lane + 63; n < N; n += 64) {
-            const int i = e * N + n;
-            T x = s.trf_x[i], y = s.trf_y[i], ps = s.trf_psi[i];   // written by this lane above
+            T x, y, ps, v;                                         // written by this lane above
+            if constexpr (HANDOFF) { x = scratch[n]; y = scratch[N + n]; ps = scratch[2 * N + n]; v = scratch[3 * N + n]; }
+            else { const int i = e * N + n; x = s.trf_x[i]; y = s.trf_y[i]; ps = s.trf_psi[i]; v = s.trf_v[i]; }
             T d, dca, vc;
-            traffic_step<T, FAST>(p, c, false, x, y, ps, s.trf_v[i], d, dca, vc);
+            traffic_step<T, FAST>(p, c, false, x, y, ps, v, d, dca, vc);
             put_traffic_obs<T, FAST>(p, row + 5 + 3 * n, d, dca, vc);
         }
     }
     if (lane == 0) {
-        if (io.ep_return) io.ep_return[e] = total;
-        if (io.ep_steps) io.ep_steps[e] = steps;
-        s.episode[e] = episode;
-        s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi; s.own_v[e] = o.v;
-        s.goal_x[e] = o.gx; s.goal_y[e] = o.gy;
-        s.steps[e] = 1;                                                   // environment.py:47
-        s.total_reward[e] = T(0);
+        if constexpr (!HANDOFF) {
+            if (io.ep_return) io.ep_return[e] = total;
+            if (io.ep_steps) io.ep_steps[e] = steps;
+            s.episode[e] = episode;
+            s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi; s.own_v[e] = o.v;
+            s.goal_x[e] = o.gx; s.goal_y[e] = o.gy;
+            s.steps[e] = 1;                                               // environment.py:47
+            s.total_reward[e] = T(0);
+        }
         put_own_obs<T, FAST>(p, row, 1, o.psi, c);
     }
     ACAS2D_STAMP(11, wave_dbg, lane, false);
@@ -911,10 +921,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
     const State<T> s = rebase(s_arg, e_wave, N);   // everything below indexes envs by `el`
     const StepIO<T> io0 = rebase(io_arg, e_wave, D);
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    // per wave: the observation tile, then (rollout) 4N+1 values of reset hand-off scratch
+    // per wave: the observation tile, then (HANDOFF) 4N+1 values of reset hand-off scratch
+    constexpr bool HANDOFF = PACKED && AUTO_RESET;   // finished envs are reset BEFORE the wave's stores
     T* tile = reinterpret_cast<T*>(lds_raw) + wib * tile_elems;
     T* row = tile + el * D;
-    T* scratch = ROLLOUT ? tile + EPW * D : nullptr;
+    T* scratch = HANDOFF ? tile + EPW * D : nullptr;
 
     ACAS2D_STAMP(0, wave, lane, false);
     ACAS2D_STAMP(1, wave, lane, false);
@@ -992,50 +1003,92 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetPara
                 io.reward[el] = rw;
                 io.done[el] = oc != 0;
                 io.outcome[el] = oc;
-                if (last && (oc == 0 || !AUTO_RESET)) {
-                    s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
-                    s.steps[el] = steps;
-                    s.total_reward[el] = total;
-                    if constexpr (!AUTO_RESET) { if (oc) s.status[el] = oc; }
+                if constexpr (!HANDOFF) {
+                    if (last && (oc == 0 || !AUTO_RESET)) {
+                        s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
+                        s.steps[el] = steps;
+                        s.total_reward[el] = total;
+                        if constexpr (!AUTO_RESET) { if (oc) s.status[el] = oc; }
+                    }
                 }
             }
         }
 
         if (t == 0) ACAS2D_STAMP(3, wave, lane, false);
-        // Flush the tile now: the stores drain while finished envs (if any) are being reset below.
-        wave_lds_fence();
         T* const obs_wave = io.obs;
-#if !defined(ACAS2D_ABLATE) || ACAS2D_ABLATE < 2
-        flush_tile<T>(tile, obs_wave, n_rows * D, lane);
-#endif
-        if (t == 0) ACAS2D_STAMP(4, wave, lane, false);
-        if constexpr (AUTO_RESET) {
-            // ---- finished envs: one bit per env (its group's lane 0), handled by the whole wave ----
+        if constexpr (HANDOFF) {
+            // ---- finished envs (one bit per env: its group's lane 0) are reset by the whole wave NOW,
+            // before anything but reward / done / outcome has been stored: the new episode's state
+            // reaches the owner lanes through LDS and leaves with the coalesced state stores and the
+            // ONE tile flush below.  (Resetting after the flush cost a second store round at the very
+            // end of the kernel -- ~12 scattered 4-byte stores per entity lane plus a re-flush of the
+            // row: 0.8 us of the 7.7 us launch at 65 536 x 8.)
+            bool fresh = false;
             unsigned long long dm = __ballot(oc != 0 && j == 0);
             while (dm) {
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);   // wave-uniform
                 dm &= dm - 1;
                 const int el_d = src / G;
-                wave_reset_env<T, FAST, NS>(p, rp, s, io, k0, k1, (uint64_t)(env_offset + e_wave + el_d), el_d, N, lane,
-                                            lane_value(total, src), lane_value(steps, src),
-                                            (uint32_t)lane_value((int)episode, src), tile + el_d * D, scratch);
-                wave_lds_fence();                         // the fresh row (and scratch) is complete
-                flush_rows<T>(tile, obs_wave, n_rows * D, el_d * D, (el_d + 1) * D, lane);
-                if constexpr (ROLLOUT) {
-                    if (el == el_d) {                     // the owner group continues with the new episode
-#pragma unroll
-                        for (int k = 0; k < C; ++k) {
-                            const int n = j * C + k;
-                            tr.x.v[k] = scratch[n]; tr.y.v[k] = scratch[N + n];
-                            tr.psi.v[k] = scratch[2 * N + n]; tr.v.v[k] = scratch[3 * N + n];
-                        }
-                        o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, scratch[4 * N], (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-                        steps = 1;                                            // environment.py:47
-                        total = T(0);
-                        episode += 1u;
+                wave_lds_fence();                         // every row of the tile is complete
+                wave_reset_env<T, FAST, NS, true>(p, rp, s, io, k0, k1, (uint64_t)(env_offset + e_wave + el_d), el_d, N,
+                                                  lane, lane_value(total, src), lane_value(steps, src),
+                                                  (uint32_t)lane_value((int)episode, src), tile + el_d * D, scratch);
+                wave_lds_fence();                         // the fresh row and the scratch are complete
+                if (el == el_d) {                         // the owner group continues with the new episode
+                    if (j == 0) {
+                        if (io.ep_return) io.ep_return[el] = total;
+                        if (io.ep_steps) io.ep_steps[el] = steps;
                     }
-                    wave_lds_fence();                     // scratch is free for the next finished env
+#pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        const int n = j * C + k;
+                        tr.x.v[k] = scratch[n]; tr.y.v[k] = scratch[N + n];
+                        tr.psi.v[k] = scratch[2 * N + n]; tr.v.v[k] = scratch[3 * N + n];
+                    }
+                    o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, scratch[4 * N], (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+                    steps = 1;                                                // environment.py:47
+                    total = T(0);
+                    episode += 1u;
+                    fresh = true;
+                    // the new traffic block: whole 16-byte vectors from the owner lanes
+                    using V = Vec<T, C>;
+                    const int i0 = el * N + j * C;
+                    *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+                    *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
                 }
+                wave_lds_fence();                         // scratch is free for the next finished env
+            }
+            if (active && j == 0) {
+                if (fresh) {                              // per-episode constants of the new episode
+                    s.episode[el] = episode;
+                    s.own_v[el] = o.v; s.goal_x[el] = o.gx; s.goal_y[el] = o.gy;
+                }
+                if (last || fresh) {
+                    s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
+                    s.steps[el] = steps;
+                    s.total_reward[el] = total;
+                }
+            }
+        }
+        // Flush the tile (generic walk: now, the stores drain while finished envs are reset below).
+        wave_lds_fence();
+#if !defined(ACAS2D_ABLATE) || ACAS2D_ABLATE < 2
+        flush_tile<T>(tile, obs_wave, n_rows * D, lane);
+#endif
+        if (t == 0) ACAS2D_STAMP(4, wave, lane, false);
+        if constexpr (AUTO_RESET && !HANDOFF) {
+            // ---- generic walk: finished envs are reset by the whole wave, entity lanes store the new
+            // state themselves and the row is flushed again ----
+            unsigned long long dm = __ballot(oc != 0 && j == 0);
+            while (dm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);   // wave-uniform
+                dm &= dm - 1;
+                const int el_d = src / G;
+                wave_reset_env<T, FAST, NS, false>(p, rp, s, io, k0, k1, (uint64_t)(env_offset + e_wave + el_d), el_d, N,
+                                                   lane, lane_value(total, src), lane_value(steps, src),
+                                                   (uint32_t)lane_value((int)episode, src), tile + el_d * D, nullptr);
+                wave_lds_fence();                         // the fresh row is complete
+                flush_rows<T>(tile, obs_wave, n_rows * D, el_d * D, (el_d + 1) * D, lane);
             }
         }
         if constexpr (ROLLOUT) wave_lds_fence();          // tile reads precede the next step's row writes

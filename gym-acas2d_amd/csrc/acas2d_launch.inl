@@ -57,12 +57,12 @@ static int check_launch(const char* what) {
 struct Geometry { unsigned grid; int tile_elems; size_t lds_bytes; };
 
 template <typename T>
-static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g, bool rollout = false) {
+static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g) {
     const int64_t epw = 64 / sh.G, envs_per_block = epw * kWavesPerBlock;
     const int64_t blocks = (n_envs + envs_per_block - 1) / envs_per_block;
     if (blocks > 0x7fffffffLL) { set_error("n_envs = %lld exceeds the grid limit", (long long)n_envs); return ACAS2D_EINVAL; }
     const int W = 16 / (int)sizeof(T);
-    const int64_t scratch = rollout ? 4 * (int64_t)n_traffic + 1 : 0;     // reset hand-off, per wave
+    const int64_t scratch = sh.packed ? 4 * (int64_t)n_traffic + 1 : 0;   // reset hand-off, per wave
     const int64_t elems = ((epw * (5 + 3 * (int64_t)n_traffic) + scratch + W - 1) / W) * W;
     const int64_t bytes = elems * kWavesPerBlock * (int64_t)sizeof(T);
     if (bytes > 64 * 1024) {
@@ -183,7 +183,7 @@ int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dS
         return ACAS2D_EINVAL;
     }
     Geometry g;
-    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g, true)) return rc;
+    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
     const ResetParams rp = make_reset_params(*cfg);
     const State<T> s = make_state<T>(*st);
