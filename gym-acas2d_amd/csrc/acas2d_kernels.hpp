@@ -31,6 +31,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "acas2d.h"
@@ -90,11 +91,20 @@ __device__ __forceinline__ Params<T> pinned(Params<T> p) {
 
 // reset distribution (game.py:80-116); evaluated in float64 for both instantiations so that a
 // seed names the same episode in f32 and f64, then rounded to T once.
-struct ResetParams {
-    double own_x0, own_y0, own_v, own_heading0, own_heading_jitter, goal_x, goal_y;
-    double t0_x, t0_y_base, t0_y_span, t0_heading_base, t0_heading_step, t0_heading_jitter;
-    double tn_x_max, tn_y_max, speed_factor_min, speed_factor_max, airspeed;
+template <typename R>
+struct ResetParamsT {
+    R own_x0, own_y0, own_v, own_heading0, own_heading_jitter, goal_x, goal_y;
+    R t0_x, t0_y_base, t0_y_span, t0_heading_base, t0_heading_step, t0_heading_jitter;
+    R tn_x_max, tn_y_max, speed_factor_min, speed_factor_max, airspeed;
 };
+// reset_kernel draws in float64 in both builds; the step kernels' in-step reset draws in the
+// element type, so the float32 build gets the constants rounded on the host (18 SGPRs instead of
+// 36 and no v_cvt_f32_f64 on the reset path).
+using ResetParams = ResetParamsT<double>;
+// (the fused rollout keeps float64 constants: with the float set the compiler settles on a register
+// allocation for that kernel that runs 7 % slower -- measured, 3.07e10 vs 3.3e10 env-steps/s)
+template <typename T, bool ROLLOUT>
+using StepResetParams = ResetParamsT<typename std::conditional<ROLLOUT, double, T>::type>;
 
 template <typename T>
 struct State {
@@ -706,8 +716,8 @@ __device__ __forceinline__ Own<T> reset_env(const ResetParams& rp, const State<T
 // Entity `ent` of a fresh episode from ONE Philox block: ent 0 = the player (only its heading is
 // random, returned in opsi; game.py:85-92), ent n + 1 = traffic n (game.py:96-116).  Bitwise the
 // same draws as reset_env() / reset_traffic().
-template <typename T>
-__device__ __forceinline__ void reset_entity(const ResetParams& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
+template <typename T, typename R>
+__device__ __forceinline__ void reset_entity(const ResetParamsT<R>& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
                                              uint32_t g_hi, uint32_t episode, int ent, T& ox, T& oy, T& opsi,
                                              T& ov) {
 #pragma clang fp contract(off)
@@ -749,8 +759,8 @@ __device__ __forceinline__ void reset_entity(const ResetParams& rp, uint32_t k0,
 // own_psi) and nothing but term_obs is stored to memory here -- the owner lanes pick the state up
 // and it leaves with the wave's ordinary, coalesced state stores and its single tile flush.  Without
 // it (generic walk) the entity lanes store the new state themselves and the caller re-flushes the row.
-template <typename T, bool FAST, int NS, bool HANDOFF>
-__device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetParams& rp, const State<T>& s,
+template <typename T, bool FAST, int NS, bool HANDOFF, typename R>
+__device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetParamsT<R>& rp, const State<T>& s,
                                                const StepIO<T>& io, uint32_t k0, uint32_t k1, uint64_t gid,
                                                int e, int N_dyn, int lane, T total, int32_t steps,
                                                uint32_t episode_prev, T* __restrict__ row,
@@ -774,7 +784,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
     // ONE Philox block per lane (a divergent player / traffic split would run two back to back).
     T tx = T(0), ty = T(0), tpsi = T(0), tv = T(0), psi_own = T(0);
     if (lane <= N) {
-        reset_entity<T>(rp, k0, k1, g_lo, g_hi, episode, lane, tx, ty, tpsi, tv);
+        reset_entity<T, R>(rp, k0, k1, g_lo, g_hi, episode, lane, tx, ty, tpsi, tv);
         if (lane == 0) {
             psi_own = tpsi;
             if constexpr (HANDOFF) scratch[4 * N] = tpsi;
@@ -789,7 +799,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
     if constexpr (NS == 0 || NS > 63) {
         for (int n = lane + 63; n < N; n += 64) {        // N > 63 only
             T x, y, ps, v;
-            reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, ps, v);
+            reset_entity<T, R>(rp, k0, k1, g_lo, g_hi, episode, n + 1, x, y, ps, v);
             if constexpr (HANDOFF) {
                 scratch[n] = x; scratch[N + n] = y; scratch[2 * N + n] = ps; scratch[3 * N + n] = v;
             } else {
@@ -900,7 +910,7 @@ __device__ __forceinline__ void flush_rows(const T* __restrict__ tile, T* __rest
 // are reset on the fly (ROLLOUT implies AUTO_RESET semantics and a packed shape).  The per-step
 // arithmetic is this same code, so rollout(T) == T x step() bit for bit.
 template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT>
-__global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, ResetParams rp, State<T> s_arg,
+__global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
                                                       int tile_elems, int n_steps) {

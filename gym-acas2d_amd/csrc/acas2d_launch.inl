@@ -27,11 +27,12 @@ static Params<T> make_params(const Acas2dConfig& c) {
     return p;
 }
 
-static ResetParams make_reset_params(const Acas2dConfig& c) {
-    return ResetParams{c.own_x0, c.own_y0, c.own_v, c.own_heading0, c.own_heading_jitter, c.goal_x,
-                       c.goal_y, c.t0_x, c.t0_y_base, c.t0_y_span, c.t0_heading_base,
-                       c.t0_heading_step, c.t0_heading_jitter, c.tn_x_max, c.tn_y_max,
-                       c.speed_factor_min, c.speed_factor_max, c.airspeed};
+template <typename R>
+static ResetParamsT<R> make_reset_params(const Acas2dConfig& c) {
+    return ResetParamsT<R>{(R)c.own_x0, (R)c.own_y0, (R)c.own_v, (R)c.own_heading0, (R)c.own_heading_jitter,
+                           (R)c.goal_x, (R)c.goal_y, (R)c.t0_x, (R)c.t0_y_base, (R)c.t0_y_span,
+                           (R)c.t0_heading_base, (R)c.t0_heading_step, (R)c.t0_heading_jitter, (R)c.tn_x_max,
+                           (R)c.tn_y_max, (R)c.speed_factor_min, (R)c.speed_factor_max, (R)c.airspeed};
 }
 
 template <typename T>
@@ -75,7 +76,7 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
 
 template <typename T, int C, int G, bool PACKED>
 static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, const Params<T>& p,
-                       const ResetParams& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
+                       const ResetParamsT<T>& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
                        int64_t env_offset, int64_t n_envs, int N) {
     if (auto_reset)
         hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
@@ -143,7 +144,7 @@ int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStep
     Geometry g;
     if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
-    const ResetParams rp = make_reset_params(*cfg);
+    const ResetParamsT<T> rp = make_reset_params<T>(*cfg);
     const State<T> s = make_state<T>(*st);
     const StepIO<T> io{(const T*)io_->actions, (T*)io_->obs, (T*)io_->reward, io_->done, io_->outcome,
                        (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
@@ -185,7 +186,7 @@ int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dS
     Geometry g;
     if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
-    const ResetParams rp = make_reset_params(*cfg);
+    const ResetParams rp = make_reset_params<double>(*cfg);
     const State<T> s = make_state<T>(*st);
     const StepIO<T> io{(const T*)io_->actions, (T*)io_->obs, (T*)io_->reward, io_->done, io_->outcome,
                        (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
@@ -210,7 +211,7 @@ int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* 
     Geometry g;
     if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
-    const ResetParams rp = make_reset_params(*cfg);
+    const ResetParams rp = make_reset_params<double>(*cfg);
     const State<T> s = make_state<T>(*st);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     if (sh.packed) {
