@@ -524,6 +524,45 @@ __device__ __forceinline__ void traffic_step(const Params<T>& p, const OwnCtx<T>
     traffic_observe<T, FAST>(p, c, tx, ty, tv, st, ct, d, dca, vc);
 }
 
+// ---- two traffic aircraft per call (float32 throughput build) ---------------------------------------
+// With 2 wavefronts per SIMD at the headline size the step kernel's arithmetic phase is bound by
+// VALU ISSUE (409 VALU instructions per wave x 4 cycles x 2 waves), not by latency.  gfx950 has
+// packed float32 math -- v_pk_mul / add / fma_f32 do two floats per lane in one issue slot -- and a
+// lane's C traffic aircraft run the same arithmetic, so the packed shapes with an even C walk their
+// traffic in PAIRS on float2 operands: the same IEEE operations in the same order as the scalar
+// functions above (bit-identical per aircraft), half the issue slots for everything that is not a
+// transcendental, a compare or a select.
+typedef float F2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ F2 m_fma(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ F2 f_sqrt(F2 x) { return F2{f_sqrt(x.x), f_sqrt(x.y)}; }
+__device__ __forceinline__ F2 f_rsq(F2 x) { return F2{f_rsq(x.x), f_rsq(x.y)}; }
+
+__device__ __forceinline__ void traffic_move2(const Params<float>& p, bool move, F2& tx, F2& ty, F2& tpsi, F2 tv,
+                                              F2& st, F2& ct) {
+    tpsi = F2{wrap360_window(tpsi.x), wrap360_window(tpsi.y)};
+    const F2 r = tpsi * Const<float>::inv360;
+    st = F2{__builtin_amdgcn_sinf(r.x), __builtin_amdgcn_sinf(r.y)};
+    ct = F2{__builtin_amdgcn_cosf(r.x), __builtin_amdgcn_cosf(r.y)};
+    const F2 tvdt = tv * p.dt;
+    if (move) { tx = m_fma(tvdt, ct, tx); ty = m_fma(tvdt, st, ty); }
+}
+
+__device__ __forceinline__ void traffic_observe2(const Params<float>& p, const OwnCtx<float>& c, F2 tx, F2 ty, F2 tv,
+                                                 F2 st, F2 ct, F2& d, F2& dca, F2& vc) {
+    const F2 tvdt = tv * p.dt;
+    const F2 v2x = rounded(tvdt * ct), v2yt = tvdt * st;
+    const F2 dx = tx - c.x, dy = ty - c.y;
+    d = f_sqrt(m_fma(dy, dy, dx * dx));
+    const F2 v12x = rounded(c.v * c.co) - rounded(tv * ct), v12y = rounded(c.v * c.so) - rounded(tv * st);
+    const F2 cross = m_fma(dy, v12x, -(dx * v12y));
+    const F2 sgn = F2{m_copysign(1.0f, v12x.x), m_copysign(1.0f, v12x.y)};
+    dca = (sgn * cross) * f_rsq(m_fma(v12y, v12y, v12x * v12x));
+    const F2 v2y = rounded((c.v * p.dt) * st);
+    const F2 x2 = tx + v2x, y2 = ty + v2yt;
+    const F2 ax = c.v1x - v2x, ay = c.v1y - v2y, bx = c.x1 - x2, by = c.y1 - y2;
+    vc = (m_fma(ay, by, ax * bx) * f_rsq(m_fma(by, by, bx * bx))) * p.inv_dt;
+}
+
 // game.py:199-203: the five player entries of the observation into the LDS row.
 template <typename T, bool FAST>
 __device__ __forceinline__ void put_own_obs(const Params<T>& p, T* row, int32_t steps, T psi, const OwnCtx<T>& c) {
@@ -593,13 +632,32 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
         // Move the whole block first and store it at once: the state write-back (half of the
         // kernel's store bytes besides obs) then drains underneath the observation arithmetic
         // instead of joining the write burst at the end of the wave.
+#ifdef ACAS2D_ABLATE
+        constexpr bool PAIRS = false;                                    // the ablation stubs live in the scalar walk
+#else
+        constexpr bool PAIRS = FAST && sizeof(T) == 4 && C % 2 == 0;    // see traffic_move2()
+#endif
         bool psi_changed = false;
         T st[C], ct[C];
+        if constexpr (PAIRS) {
 #pragma unroll
-        for (int k = 0; k < C; ++k) {
-            const T psi_in = tr.psi.v[k];
-            traffic_move<T, FAST>(p, move, tr.x.v[k], tr.y.v[k], tr.psi.v[k], tr.v.v[k], st[k], ct[k]);
-            psi_changed |= (tr.psi.v[k] != psi_in);
+            for (int k = 0; k < C; k += 2) {
+                F2 x{tr.x.v[k], tr.x.v[k + 1]}, y{tr.y.v[k], tr.y.v[k + 1]}, ps{tr.psi.v[k], tr.psi.v[k + 1]};
+                const F2 v{tr.v.v[k], tr.v.v[k + 1]}, ps_in = ps;
+                F2 s2, c2;
+                traffic_move2(p, move, x, y, ps, v, s2, c2);
+                tr.x.v[k] = x.x; tr.x.v[k + 1] = x.y; tr.y.v[k] = y.x; tr.y.v[k + 1] = y.y;
+                tr.psi.v[k] = ps.x; tr.psi.v[k + 1] = ps.y;
+                st[k] = s2.x; st[k + 1] = s2.y; ct[k] = c2.x; ct[k + 1] = c2.y;
+                psi_changed |= (ps.x != ps_in.x) | (ps.y != ps_in.y);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const T psi_in = tr.psi.v[k];
+                traffic_move<T, FAST>(p, move, tr.x.v[k], tr.y.v[k], tr.psi.v[k], tr.v.v[k], st[k], ct[k]);
+                psi_changed |= (tr.psi.v[k] != psi_in);
+            }
         }
 #if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 5
         asm volatile("" :: "v"(tr.x.v[0]), "v"(tr.y.v[0]));
@@ -616,13 +674,27 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
 #endif
             if (psi_changed) *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;   // injected headings >= 360 only
         }
+        if constexpr (PAIRS) {
 #pragma unroll
-        for (int k = 0; k < C; ++k) {
-            T d, dca, vc;
-            traffic_observe<T, FAST>(p, c, tr.x.v[k], tr.y.v[k], tr.v.v[k], st[k], ct[k], d, dca, vc);
-            coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
-            put_traffic_obs<T, FAST>(p, row + 5 + 3 * (j * C + k), d, dca, vc);
-            if (k == 0) { vc0 = vc; dc0 = dca; }
+            for (int k = 0; k < C; k += 2) {
+                F2 d, dca, vc;
+                traffic_observe2(p, c, F2{tr.x.v[k], tr.x.v[k + 1]}, F2{tr.y.v[k], tr.y.v[k + 1]},
+                                 F2{tr.v.v[k], tr.v.v[k + 1]}, F2{st[k], st[k + 1]}, F2{ct[k], ct[k + 1]}, d, dca, vc);
+                coll |= ((d.x < p.collision_dist) | (d.y < p.collision_dist)) ? 1 : 0;   // game.py:185-189
+                const F2 dn = d * p.inv_d_sep_max, cn = dca * p.inv_d_cpa_max, vn = vc * p.inv_v_closing_max;
+                T* q = row + 5 + 3 * (j * C + k);                                 // game.py:205-210
+                q[0] = dn.x; q[1] = cn.x; q[2] = vn.x; q[3] = dn.y; q[4] = cn.y; q[5] = vn.y;
+                if (k == 0) { vc0 = vc.x; dc0 = dca.x; }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                T d, dca, vc;
+                traffic_observe<T, FAST>(p, c, tr.x.v[k], tr.y.v[k], tr.v.v[k], st[k], ct[k], d, dca, vc);
+                coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
+                put_traffic_obs<T, FAST>(p, row + 5 + 3 * (j * C + k), d, dca, vc);
+                if (k == 0) { vc0 = vc; dc0 = dca; }
+            }
         }
     } else {
         for (int n = j; n < N; n += G) {
