@@ -537,15 +537,25 @@ __device__ __forceinline__ F2 m_fma(F2 a, F2 b, F2 c) { return __builtin_element
 __device__ __forceinline__ F2 f_sqrt(F2 x) { return F2{f_sqrt(x.x), f_sqrt(x.y)}; }
 __device__ __forceinline__ F2 f_rsq(F2 x) { return F2{f_rsq(x.x), f_rsq(x.y)}; }
 
-__device__ __forceinline__ void traffic_move2(const Params<float>& p, bool move, F2& tx, F2& ty, F2& tpsi, F2 tv,
-                                              F2& st, F2& ct) {
+// traffic_move() in two halves: the heading part (wrap, sin, cos) and the Euler step.  Traffic flies
+// straight (a_lat = 0, game.py:232-241), so the heading part gives the same result every step of an
+// episode; the fused rollout keeps it in registers (TrigCache) and redoes it only after a reset.
+__device__ __forceinline__ void traffic_trig2(F2& tpsi, F2& st, F2& ct) {
     tpsi = F2{wrap360_window(tpsi.x), wrap360_window(tpsi.y)};
     const F2 r = tpsi * Const<float>::inv360;
     st = F2{__builtin_amdgcn_sinf(r.x), __builtin_amdgcn_sinf(r.y)};
     ct = F2{__builtin_amdgcn_cosf(r.x), __builtin_amdgcn_cosf(r.y)};
+}
+__device__ __forceinline__ void traffic_advance2(const Params<float>& p, bool move, F2& tx, F2& ty, F2 tv, F2 st, F2 ct) {
     const F2 tvdt = tv * p.dt;
     if (move) { tx = m_fma(tvdt, ct, tx); ty = m_fma(tvdt, st, ty); }
 }
+template <typename T, int C>
+struct TrigCache {
+    T st[C], ct[C];
+    bool valid = false;      // st / ct belong to the headings in the lane's registers
+    bool dirty = false;      // a wrap changed a heading that has not been stored yet
+};
 
 __device__ __forceinline__ void traffic_observe2(const Params<float>& p, const OwnCtx<float>& c, F2 tx, F2 ty, F2 tv,
                                                  F2 st, F2 ct, F2& d, F2& dca, F2& vc) {
@@ -620,7 +630,8 @@ __device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int i0)
 template <typename T, int C, int G, bool PACKED, bool FAST>
 __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
                                            int e, int j, int N, int32_t steps, bool move,
-                                           Traffic<T, C>& tr, T* __restrict__ row, bool store_traffic = true) {
+                                           Traffic<T, C>& tr, T* __restrict__ row, bool store_traffic = true,
+                                           TrigCache<T, C>* tc = nullptr) {
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
     Seen<T> r;
     r.d_goal = c.d_goal; r.h_goal = c.h_goal; r.d_dev = c.d_dev;
@@ -640,16 +651,30 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
         bool psi_changed = false;
         T st[C], ct[C];
         if constexpr (PAIRS) {
+            if (tc != nullptr && tc->valid) {
+#pragma unroll
+                for (int k = 0; k < C; ++k) { st[k] = tc->st[k]; ct[k] = tc->ct[k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; k += 2) {
+                    F2 ps{tr.psi.v[k], tr.psi.v[k + 1]}, s2, c2;
+                    const F2 ps_in = ps;
+                    traffic_trig2(ps, s2, c2);
+                    tr.psi.v[k] = ps.x; tr.psi.v[k + 1] = ps.y;
+                    st[k] = s2.x; st[k + 1] = s2.y; ct[k] = c2.x; ct[k + 1] = c2.y;
+                    psi_changed |= (ps.x != ps_in.x) | (ps.y != ps_in.y);
+                }
+                if (tc != nullptr) {
+#pragma unroll
+                    for (int k = 0; k < C; ++k) { tc->st[k] = st[k]; tc->ct[k] = ct[k]; }
+                    tc->valid = true;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < C; k += 2) {
-                F2 x{tr.x.v[k], tr.x.v[k + 1]}, y{tr.y.v[k], tr.y.v[k + 1]}, ps{tr.psi.v[k], tr.psi.v[k + 1]};
-                const F2 v{tr.v.v[k], tr.v.v[k + 1]}, ps_in = ps;
-                F2 s2, c2;
-                traffic_move2(p, move, x, y, ps, v, s2, c2);
+                F2 x{tr.x.v[k], tr.x.v[k + 1]}, y{tr.y.v[k], tr.y.v[k + 1]};
+                traffic_advance2(p, move, x, y, F2{tr.v.v[k], tr.v.v[k + 1]}, F2{st[k], st[k + 1]}, F2{ct[k], ct[k + 1]});
                 tr.x.v[k] = x.x; tr.x.v[k + 1] = x.y; tr.y.v[k] = y.x; tr.y.v[k + 1] = y.y;
-                tr.psi.v[k] = ps.x; tr.psi.v[k + 1] = ps.y;
-                st[k] = s2.x; st[k + 1] = s2.y; ct[k] = c2.x; ct[k + 1] = c2.y;
-                psi_changed |= (ps.x != ps_in.x) | (ps.y != ps_in.y);
             }
         } else {
 #pragma unroll
@@ -659,6 +684,8 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
                 psi_changed |= (tr.psi.v[k] != psi_in);
             }
         }
+        // rollout: a wrapped heading waits in registers for the last step's store
+        if (tc != nullptr) { tc->dirty |= psi_changed; psi_changed = tc->dirty; }
 #if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 5
         asm volatile("" :: "v"(tr.x.v[0]), "v"(tr.y.v[0]));
         if (false) {
@@ -672,7 +699,10 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
             *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
             *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
 #endif
-            if (psi_changed) *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;   // injected headings >= 360 only
+            if (psi_changed) {                                                  // injected headings >= 360 only
+                *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;
+                if (tc != nullptr) tc->dirty = false;
+            }
         }
         if constexpr (PAIRS) {
 #pragma unroll
@@ -1027,6 +1057,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         else frozen = s.status[el] != 0;                                   // game.py:243-245
     }
 
+    TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
     const int T_steps = ROLLOUT ? n_steps : 1;
     T action_next = active ? io0.actions[el] : T(0);       // step t+1's action is fetched during step t
     for (int t = 0; t < T_steps; ++t) {
@@ -1064,7 +1095,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // `episode` is first USED in the reset loop far below; without this use the compiler waits
             // for its load there with s_waitcnt vmcnt(0) -- i.e. for every store issued since.
             asm volatile("" : "+v"(episode));
-            Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last);
+            Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last,
+                                                       ROLLOUT ? &trig : nullptr);
 
             // game.py:249-292 evaluate()
             T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
@@ -1132,6 +1164,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                     total = T(0);
                     episode += 1u;
                     fresh = true;
+                    trig.valid = false; trig.dirty = false;   // new headings (stored below)
                     // the new traffic block: whole 16-byte vectors from the owner lanes
                     using V = Vec<T, C>;
                     const int i0 = el * N + j * C;

@@ -518,6 +518,33 @@ def test_rollout_equals_sequential_steps(g, dtype_name, N, E, T):
         g.ACAS2DVecEnv(16, 5, device=dev, dtype=dtype).rollout(torch.zeros(2, 16, device=dev, dtype=dtype))
 
 
+@pytest.mark.parametrize("dtype_name", ("float32", "float64"))
+def test_rollout_wraps_and_stores_injected_headings_like_steps(g, dtype_name):
+    """aircraft.py:22 wraps a heading (psi % 360) on every step.  Headings injected outside [0, 360)
+    are wrapped by the first step and written back; the fused rollout keeps the traffic's sin / cos
+    in registers across steps and must still leave the same (wrapped) state behind."""
+    dtype = getattr(torch, dtype_name)
+    E, N, T = 256, 8, 7
+    cfg = g.ACAS2DConfig(n_traffic=N)
+    own, trf, goal = H.parity_reset_states(cfg, 99, 0, E)
+    own[:, 2] += 360.0                       # 357..363 -> 717..723: inside the float32 window (-360, 720)
+    own[:, 2] = np.minimum(own[:, 2], 719.0)
+    trf[:, :, 2] += 360.0 * (np.arange(N)[None, :] % 2)
+    a = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=3)
+    b = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=3)
+    for v in (a, b):
+        v.set_state(own, trf, goal, np.zeros(E, np.int32), observe=False)
+    gen = torch.Generator(device="cuda:0").manual_seed(2)
+    actions = torch.rand(T, E, generator=gen, device="cuda:0", dtype=dtype) * 2 - 1
+    out = a.rollout(actions)
+    for t in range(T):
+        obs, rew, done, _ = b.step(actions[t])
+        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew), t
+    for name in ("own_psi", "trf_psi", "trf_x", "trf_y", "own_x", "own_y", "steps", "episode"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert float(a.trf_psi.max()) < 360.0 and float(a.own_psi.max()) < 360.0
+
+
 def test_lazy_infos_and_vecenv_surface(g):
     E, N = 256, 64                          # N = 64: episodes last ~8 steps -> many dones
     env = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, seed=3)
