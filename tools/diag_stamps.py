@@ -3,10 +3,14 @@
 
 Loads libacas2d_hip_diag.so (make -C gym-acas2d_amd/csrc diag: same kernels + in-kernel
 s_memtime / s_memrealtime stamps per wave), runs a few steps and prints, per phase, the
-distribution over waves.  Never quote this build's run time (stamps forbid overlaps the real
-kernel has); read its SHARES.  Stamps per wave: 0 realtime@start, 1 clk@start, 2 clk after all
-loads landed, 3 clk after observe/evaluate + state stores issued, 4 clk after the obs flush is issued,
-5 clk after the reset section (incl. re-flush of reset rows), 6 clk after all stores are acknowledged, 7 realtime@end.
+distribution over waves.  Never quote this build's run time: every stamp is an s_memtime round trip
+(~500 cycles, measured with two back-to-back stamps), so sections that hold several stamps -- the
+reset section has four -- read ~2000 cycles long before they do anything.  Read the SHARES, and use
+product-build experiments (tools/README.md) for absolute costs.  Stamps per wave: 0 realtime@start,
+1 clk@start, 2 clk after all loads landed, 3 clk after observe/evaluate (reward/done/outcome stores
+issued), 4 clk after [packed shapes: the reset of finished envs, then] the state stores and the tile
+flush are issued, 5 clk after the generic walk's late reset (packed shapes: == 4), 6 clk after all
+stores are acknowledged, 7 realtime@end; 8..11 inside the reset of a finished env.
 """
 import argparse
 import ctypes as C
@@ -59,15 +63,16 @@ for _ in range(args.steps):
     span_us = (st[:, 7].max() - t0) / 100.0           # s_memrealtime ticks at 100 MHz
     clk = np.median((st[:, 6] - st[:, 1]) / np.maximum((st[:, 7] - st[:, 0]) / 100.0, 1e-9)) / 1e3   # GHz
     ph = {"start skew us": (st[:, 0] - t0) / 100.0,
-          "loads": st[:, 2] - st[:, 1], "compute": st[:, 3] - st[:, 2], "flush issue": st[:, 4] - st[:, 3],
-          "reset": st[:, 5] - st[:, 4], "store drain": st[:, 6] - st[:, 5],
+          "loads": st[:, 2] - st[:, 1], "compute": st[:, 3] - st[:, 2], "reset+stores+flush": st[:, 4] - st[:, 3],
+          "late reset": st[:, 5] - st[:, 4], "store drain": st[:, 6] - st[:, 5],
           "wave total": st[:, 6] - st[:, 1]}
     rs = st[st[:, 8] > 0]
     if len(rs):
-        inner.append([np.median(rs[:, 8] - rs[:, 4]), np.median(rs[:, 9] - rs[:, 8]), np.median(rs[:, 10] - rs[:, 9]),
-                      np.median(rs[:, 11] - rs[:, 10]), np.median(rs[:, 5] - rs[:, 11])])
+        inner.append([np.median(rs[:, 8] - rs[:, 3]), np.median(rs[:, 9] - rs[:, 8]), np.median(rs[:, 10] - rs[:, 9]),
+                      np.median(rs[:, 11] - rs[:, 10]), np.median(rs[:, 4] - rs[:, 11])])
     rows.append((span_us, clk, {k: (np.median(v), np.percentile(v, 99), v.max()) for k, v in ph.items()},
-                 wave_done.mean(), np.median((st[:, 5] - st[:, 4])[wave_done]) if wave_done.any() else 0,
+                 wave_done.mean(), (np.median((st[:, 5] - st[:, 3])[wave_done]) - np.median((st[:, 5] - st[:, 3])[~wave_done]))
+                 if wave_done.any() and (~wave_done).any() else 0,
                  (st[:, 7] - t0).argmax(), wave_done[(st[:, 7] - t0).argmax()]))
 print("config: %d envs x %d traffic, shape %s, %d waves" % (args.envs, args.traffic, geo, n_waves))
 span = np.array([r[0] for r in rows])
@@ -78,10 +83,10 @@ print("phase (cycles unless noted): median over waves | p99 | max   [medians ove
 for k in rows[0][2]:
     a = np.array([r[2][k] for r in rows])
     print("  %-14s %10.1f | %10.1f | %10.1f" % (k, *np.median(a, axis=0)))
-print("waves with a finished env: %.1f %%; their reset section: %.0f cycles (median)" %
+print("waves with a finished env: %.1f %%; they spend %.0f cycles more than the others between compute and the last store issue (median)" %
       (100 * np.mean([r[3] for r in rows]), np.median([r[4] for r in rows])))
 print("last-finishing wave had a finished env in %d of %d launches" % (sum(bool(r[6]) for r in rows), len(rows)))
 if inner:
     m = np.median(np.array(inner), axis=0)
-    print("reset section of waves with a finished env (last reset in the wave), cycles: ballot/shfl entry %.0f | "
-          "term_obs + Philox + state %.0f | own_context %.0f | traffic obs + stores %.0f | fence + re-flush %.0f" % tuple(m))
+    print("waves with a finished env (last reset in the wave), cycles incl. ~500 per stamp: entry %.0f | term_obs + Philox + "
+          "hand-off %.0f | own_context %.0f | traffic obs %.0f | pick-up + state stores + flush %.0f" % tuple(m))
