@@ -11,6 +11,14 @@ normalised per minibatch) on E parallel envs: rollouts, GAE and the updates all 
 The network uses SB3's `MlpPolicy` parameter names (separate 2x64 tanh actor / critic), so the
 reference's trained zips load as initial weights (`ActorCritic.load_sb3_state_dict`) and a policy
 trained here can be evaluated with `policy.SB3ActorPolicy` / `evaluate_policy`.
+
+The loop is launch-bound (a 2x64 MLP on a few thousand rows: ~25 small kernels per env step, ~60 per
+minibatch update), so on the GPU it runs from three hipGraphs (`use_graphs`, default on CUDA
+devices): ONE env step of the collector (policy forward, sample, log-prob, the step kernel, the
+buffer writes -- the time index is a device counter, so the same graph is replayed n_steps times),
+the GAE recursion, and ONE minibatch update (gather by a static index buffer, losses, backward,
+gradient clipping, capturable Adam).  No host synchronisation inside an iteration; episode
+statistics are read once per iteration from the [T, E] side-channel buffers.
 """
 import dataclasses
 import math
@@ -98,20 +106,148 @@ def compute_gae(rewards, values, dones, last_value, gamma, lam):
     return adv, adv + values
 
 
+LOG_SQRT_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+def _normal_logp(mean, log_std, x):
+    """log N(x; mean, exp(log_std)) summed over the action dimension (torch.distributions.Normal.log_prob)."""
+    return (-((x - mean) ** 2) / (2.0 * (2.0 * log_std).exp()) - log_std - LOG_SQRT_2PI).sum(-1)
+
+
 class PPOTrainer:
-    def __init__(self, venv, config=None, policy=None):
+    def __init__(self, venv, config=None, policy=None, use_graphs=None):
         self.venv = venv
         self.cfg = config or PPOConfig()
         torch.manual_seed(self.cfg.seed)
         self.device = venv.device
         self.policy = (policy or ActorCritic(venv.obs_dim)).to(self.device)
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5)
-        self.obs = venv.reset().clone()
+        self.use_graphs = (torch.device(self.device).type == "cuda") if use_graphs is None else bool(use_graphs)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5,
+                                    capturable=self.use_graphs)
+        self.obs = venv.reset().to(torch.float32).clone()
+        # Exact parallel flight makes the reference's d_cpa 0/0 = NaN (kinematics.py:48), and its reward
+        # with it when the aircraft is traffic[0]; the engine reproduces that.  In float64 it all but
+        # never happens; in float32 headings coincide bit for bit about once per 2e7 env steps, and one
+        # NaN poisons PPO for good -- so the collector replaces non-finite observations / rewards by 0
+        # (what SB3 users wrap such envs in VecCheckNan for) and counts the events.
+        self.nan_events = torch.zeros((), dtype=torch.int64, device=self.device)
         self.num_timesteps = 0
         self.ep_returns, self.ep_lengths, self.ep_outcomes = [], [], []
+        self._graphs = None
+
+    # ---- rollout buffers (static: the graphs write into them) ------------------------------------
+    def _alloc(self):
+        E, T, D, dev = self.venv.num_envs, self.cfg.n_steps, self.venv.obs_dim, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.b_obs = torch.empty(T, E, D, **f32)
+        self.b_act = torch.empty(T, E, 1, **f32)
+        self.b_logp, self.b_val, self.b_rew = (torch.empty(T, E, **f32) for _ in range(3))
+        self.b_adv, self.b_ret, self.b_epret = (torch.empty(T, E, **f32) for _ in range(3))
+        self.b_done = torch.empty(T, E, dtype=torch.bool, device=dev)
+        self.b_eplen = torch.empty(T, E, dtype=torch.int32, device=dev)
+        self.b_outcome = torch.empty(T, E, dtype=torch.uint8, device=dev)
+        self.t_idx = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def _collect_step(self):
+        """One env step of SB3's collect_rollouts into row t_idx of the buffers (graph-capturable:
+        no host reads, the row index lives on the device)."""
+        v, t = self.venv, self.t_idx
+        mean, value = self.policy.forward(self.obs)
+        log_std = self.policy.log_std
+        action = mean + log_std.exp() * torch.randn_like(mean)
+        logp = _normal_logp(mean, log_std, action)
+        self.b_obs.index_copy_(0, t, self.obs.unsqueeze(0))
+        self.b_act.index_copy_(0, t, action.unsqueeze(0))
+        self.b_val.index_copy_(0, t, value.unsqueeze(0))
+        self.b_logp.index_copy_(0, t, logp.unsqueeze(0))
+        # the env sees the clipped action, the buffer keeps the raw one (SB3 collect_rollouts)
+        v.actions_buffer.copy_(action.clamp(-1.0, 1.0).reshape(-1))
+        v.step_inplace()
+        out = v.outputs
+        rew, nxt = out["reward"].to(torch.float32), out["obs"].to(torch.float32)
+        self.nan_events.add_(torch.isnan(rew).sum() + torch.isnan(nxt).any(-1).sum())
+        self.b_rew.index_copy_(0, t, torch.nan_to_num(rew, nan=0.0).unsqueeze(0))
+        self.b_done.index_copy_(0, t, out["done"].view(torch.bool).unsqueeze(0))
+        self.b_epret.index_copy_(0, t, out["episode_return"].to(torch.float32).unsqueeze(0))
+        self.b_eplen.index_copy_(0, t, out["episode_steps"].unsqueeze(0))
+        self.b_outcome.index_copy_(0, t, out["outcome"].unsqueeze(0))
+        self.obs.copy_(torch.nan_to_num(nxt, nan=0.0))
+        t.add_(1)
+
+    def _gae(self):
+        _, last_value = self.policy.forward(self.obs)
+        adv, ret = compute_gae(self.b_rew, self.b_val, self.b_done, last_value, self.cfg.gamma, self.cfg.gae_lambda)
+        self.b_adv.copy_(adv)
+        self.b_ret.copy_(ret)
+
+    def _minibatch(self):
+        """One PPO minibatch update on the rows named by the static index buffer."""
+        cfg, idx = self.cfg, self.mb_idx
+        T, E = self.cfg.n_steps, self.venv.num_envs
+        flat = lambda x: x.reshape(T * E, *x.shape[2:])  # noqa: E731
+        obs, act = flat(self.b_obs)[idx], flat(self.b_act)[idx]
+        old_logp, a, ret = flat(self.b_logp)[idx], flat(self.b_adv)[idx], flat(self.b_ret)[idx]
+        # (torch.distributions validates its arguments with a host read: not capturable)
+        mean, value = self.policy.forward(obs)
+        log_std = self.policy.log_std
+        logp = _normal_logp(mean, log_std, act)
+        a = (a - a.mean()) / (a.std() + 1e-8)
+        ratio = (logp - old_logp).exp()
+        pg = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+        vf = torch.nn.functional.mse_loss(value, ret)
+        ent = -(0.5 + LOG_SQRT_2PI + log_std).sum()       # Normal entropy, state-independent
+        loss = pg + cfg.ent_coef * ent + cfg.vf_coef * vf
+        loss.backward()
+        nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
+        self.opt.step()
+        return pg.detach(), vf.detach()
+
+    def _capture(self):
+        """Warm the three bodies up on a side stream, then capture them (PyTorch's whole-network
+        capture recipe: gradients are None at capture time, so backward assigns static buffers)."""
+        self._alloc()
+        n = self.cfg.n_steps * self.venv.num_envs
+        self.mb_idx = torch.zeros(min(self.cfg.batch_size, n), dtype=torch.int64, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            with torch.no_grad():
+                for _ in range(2):
+                    self.t_idx.zero_()
+                    self._collect_step()
+                self._gae()
+            for _ in range(2):
+                self.opt.zero_grad(set_to_none=True)
+                self._minibatch()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        g_step, g_gae, g_upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.t_idx.zero_()
+        with torch.no_grad():
+            with torch.cuda.graph(g_step):
+                self._collect_step()
+            with torch.cuda.graph(g_gae):
+                self._gae()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g_upd):
+            self._pg, self._vf = self._minibatch()
+        self._graphs = (g_step, g_gae, g_upd)
 
     def collect(self):
         cfg, E, T = self.cfg, self.venv.num_envs, self.cfg.n_steps
+        if self.use_graphs:
+            if self._graphs is None:
+                self._capture()
+            self.t_idx.zero_()
+            for _ in range(T):
+                self._graphs[0].replay()
+            self._graphs[1].replay()
+            done = self.b_done
+            if bool(done.any()):                          # the iteration's one host synchronisation
+                self.ep_returns.append(self.b_epret[done].cpu())
+                self.ep_lengths.append((self.b_eplen[done] - 1).cpu())
+                self.ep_outcomes.append(self.b_outcome[done].cpu())
+            self.num_timesteps += T * E
+            return None
         dev = self.device
         b_obs = torch.empty(T, E, self.venv.obs_dim, dtype=torch.float32, device=dev)
         b_act = torch.empty(T, E, 1, dtype=torch.float32, device=dev)
@@ -127,20 +263,30 @@ class PPOTrainer:
                 b_logp[t] = dist.log_prob(action).sum(-1)
                 # the env sees the clipped action, the buffer keeps the raw one (SB3 collect_rollouts)
                 obs, rew, done, infos = self.venv.step(action.clamp(-1.0, 1.0).to(self.venv.dtype))
-                b_rew[t], b_done[t] = rew.to(torch.float32), done
+                self.nan_events += torch.isnan(rew).sum() + torch.isnan(obs).any(-1).sum()
+                b_rew[t], b_done[t] = torch.nan_to_num(rew.to(torch.float32), nan=0.0), done
                 if bool(done.any()):
                     self.ep_returns.append(infos.episode_return[done].float().cpu())
                     self.ep_lengths.append((infos.episode_steps[done] - 1).cpu())
                     self.ep_outcomes.append(infos.outcome[done].cpu())
-                self.obs = obs.clone()
+                self.obs = torch.nan_to_num(obs.to(torch.float32), nan=0.0)
             _, last_value = self.policy.forward(self.obs)
             adv, ret = compute_gae(b_rew, b_val, b_done, last_value, cfg.gamma, cfg.gae_lambda)
         self.num_timesteps += T * E
         flat = lambda x: x.reshape(T * E, *x.shape[2:])  # noqa: E731
         return flat(b_obs), flat(b_act), flat(b_logp), flat(adv), flat(ret), flat(b_val)
 
-    def update(self, obs, act, old_logp, adv, ret, old_val):
+    def update(self, obs=None, act=None, old_logp=None, adv=None, ret=None, old_val=None):
         cfg = self.cfg
+        if self.use_graphs:
+            n, B = cfg.n_steps * self.venv.num_envs, self.mb_idx.numel()
+            for _ in range(cfg.n_epochs):
+                perm = torch.randperm(n, device=self.device)
+                for i in range(0, n - B + 1, B):          # whole minibatches (static shapes)
+                    self.mb_idx.copy_(perm[i:i + B])
+                    self._graphs[2].replay()
+            return {"pg_loss": self._pg.item(), "value_loss": self._vf.item(),
+                    "std": self.policy.log_std.detach().exp().item()}
         n = obs.shape[0]
         stats = {}
         for _ in range(cfg.n_epochs):
@@ -179,11 +325,12 @@ class PPOTrainer:
         history = []
         while self.num_timesteps < total_timesteps:
             batch = self.collect()
-            stats = self.update(*batch)
+            stats = self.update() if batch is None else self.update(*batch)
             it += 1
             ep = self.recent_episodes() or {}
             rec = {"iteration": it, "timesteps": self.num_timesteps,
-                   "fps": self.num_timesteps / max(time.time() - t0, 1e-9), **ep, **stats}
+                   "fps": self.num_timesteps / max(time.time() - t0, 1e-9), **ep, **stats,
+                   "nan_events": int(self.nan_events)}
             history.append(rec)
             if log:
                 log(rec)

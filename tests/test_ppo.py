@@ -54,8 +54,8 @@ def _eval_on_reference_episodes(g, policy):
 
 @pytest.mark.gpu
 def test_short_ppo_run_learns():
-    """16 iterations (4.2 M env steps, ~20 s) of the configuration that solves the task in 60 M
-    (profiles/r01_ppo_train_1024x256.jsonl).  Judged by the deterministic evaluation on the
+    """16 iterations (4.2 M env steps, ~8 s from hipGraphs) of the configuration that solves the task
+    in 60 M (profiles/r01_ppo_train_graphs_1024x256.jsonl).  Judged by the deterministic evaluation on the
     reference's 100 test episodes: the untrained policy's mean action is ~0, i.e. the reference's
     constant-action baseline (58 collisions / 42 goals, mean return -70.8, notebook
     baseline_ACAS2D_PPO_11_100.ipynb:280); by then PPO has learned to stay clear of the traffic."""
@@ -69,3 +69,18 @@ def test_short_ppo_run_learns():
     after = _eval_on_reference_episodes(g, tr.policy)
     assert (after["outcome"] == 2).sum() <= 10, np.bincount(after["outcome"], minlength=4)
     assert after["total_reward"].mean() > before["total_reward"].mean() + 50
+
+
+@pytest.mark.gpu
+def test_eager_ppo_path_still_runs_and_counts_nan_events():
+    """use_graphs=False is the same algorithm launched op by op (the debugging path)."""
+    import gym_acas2d_amd as g
+    venv = g.ACAS2DVecEnv(256, 1, device="cuda:0", dtype=torch.float32, seed=13)
+    tr = g.PPOTrainer(venv, g.PPOConfig(n_steps=32, batch_size=2048), use_graphs=False)
+    hist = tr.learn(2 * 32 * 256, log=None)
+    assert len(hist) == 2 and np.isfinite(hist[-1]["value_loss"]) and hist[-1]["nan_events"] == 0
+    tg = g.PPOTrainer(g.ACAS2DVecEnv(256, 1, device="cuda:0", dtype=torch.float32, seed=13),
+                      g.PPOConfig(n_steps=32, batch_size=2048))
+    assert tg.use_graphs
+    hg = tg.learn(2 * 32 * 256, log=None)
+    assert len(hg) == 2 and np.isfinite(hg[-1]["value_loss"]) and hg[-1]["timesteps"] == hist[-1]["timesteps"]
