@@ -285,14 +285,17 @@ template <typename T, bool FAST>
 __device__ __forceinline__ T step_reward_5(const Params<T>& p, T v_closing, T psi, T phi, T d_cpa,
                                             T d_goal, T d_dev) {
     if constexpr (FAST) {
-        T hr = pow4(T(1) - delta_heading(psi, phi) * T(1.0 / 180.0));
+        // every 1 - a*b below is an EXPLICIT fma: left to -ffp-contract=fast, different instantiations
+        // of the kernel (work shapes, rollout / policy variants) fused some of them and not others,
+        // and the same state gave rewards one ulp apart depending on the shape that stepped it
+        T hr = pow4(m_fma(-delta_heading(psi, phi), T(1.0 / 180.0), T(1)));
         if (v_closing <= T(0)) {
             T car = py_min1(pow4(d_cpa * p.inv_safe_distance));
             T ad = m_abs(d_dev);
-            T pdr = (ad > p.rw_d_dev_max) ? T(0) : f_sqrt(T(1) - ad * p.inv_rw_d_dev_max);
-            return hr * car * pdr;
+            T pdr = (ad > p.rw_d_dev_max) ? T(0) : f_sqrt(m_fma(-ad, p.inv_rw_d_dev_max, T(1)));
+            return (hr * car) * pdr;
         }
-        return hr * py_min1(pow4(T(1) - d_goal * p.inv_rw_d_goal_max));
+        return hr * py_min1(pow4(m_fma(-d_goal, p.inv_rw_d_goal_max, T(1))));
     } else {
         T hr = pow4(T(1) - delta_heading(psi, phi) / T(180));
         if (v_closing <= T(0)) {
@@ -438,7 +441,7 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
         c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
         const T gdx = o.gx - o.x, gdy = o.gy - o.y;
         c.d_goal = f_sqrt(m_fma(gdy, gdy, gdx * gdx));
-        c.h_goal = atan2_rev(gdy, gdx) * T(360);
+        c.h_goal = rounded(atan2_rev(gdy, gdx) * T(360));   // materialised: evaluate() subtracts it from psi
         c.d_dev = gdy;            // d_goal * sin(atan2(gdy, gdx)) == gdy          (game.py:175-180)
     } else {
         m_sincos(deg2rad_ref(o.psi), &c.so, &c.co);
@@ -1005,18 +1008,79 @@ __device__ __forceinline__ void flush_rows(const T* __restrict__ tile, T* __rest
     }
 }
 
+// ---- the policy inside the rollout (testing_main.py:69-105's loop in one launch) -----------
+// SB3 1.1.0 MlpPolicy actor: obs -> Linear(D,64) tanh -> Linear(64,64) tanh -> Linear(64,1), the
+// deterministic action = clip(mean, -1, 1) (policies.py predict()).  One lane per env (G == 1
+// shapes): the lane keeps its 64 + 64 hidden activations in registers as 32 + 32 float2 accumulators;
+// the weights are wave-uniform, so they stream through SGPRs from the constant address space
+// (s_load_dwordx16) straight into v_pk_fma_f32's scalar operand -- 2 368 packed FMAs per env-step
+// at D = 8, no LDS, no vector loads.  Weights arrive TRANSPOSED ([in][out], row-major) so that one
+// input's 64 outgoing weights are contiguous.  float32 math in both builds (the reference's
+// policy.predict() runs its float32 torch module on float32-cast observations).
+#define ACAS2D_AS4 __attribute__((address_space(4)))
+struct PolicyW {
+    const float *w1t, *b1, *w2t, *b2, *w3, *b3;      // [D][64], [64], [64][64], [64], [64], [1]
+    void* actions_out;                               // T[n_steps][E]: the action each step took
+    const void* obs_in;                              // T[E][D]: the observation the first action is taken on
+};
+constexpr int kPolicyHidden = 64;
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on v_exp_f32 / v_rcp_f32: abs error < 2e-7 over the reals
+// (saturates cleanly: exp -> inf gives 1, exp -> 0 gives -1).
+__device__ __forceinline__ float tanh_hw(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);          // 2 log2(e)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+template <int D>
+__device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&x)[D]) {
+    constexpr int H2 = kPolicyHidden / 2;
+    const F2 ACAS2D_AS4* w1 = (const F2 ACAS2D_AS4*)pw.w1t;
+    const F2 ACAS2D_AS4* b1 = (const F2 ACAS2D_AS4*)pw.b1;
+    const F2 ACAS2D_AS4* w2 = (const F2 ACAS2D_AS4*)pw.w2t;
+    const F2 ACAS2D_AS4* b2 = (const F2 ACAS2D_AS4*)pw.b2;
+    const F2 ACAS2D_AS4* w3 = (const F2 ACAS2D_AS4*)pw.w3;
+    const float ACAS2D_AS4* b3 = (const float ACAS2D_AS4*)pw.b3;
+    F2 h[H2], g[H2];
+#pragma unroll
+    for (int i = 0; i < H2; ++i) h[i] = b1[i];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const F2 xk = F2{x[k], x[k]};
+#pragma unroll
+        for (int i = 0; i < H2; ++i) h[i] = __builtin_elementwise_fma(w1[k * H2 + i], xk, h[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < H2; ++i) { h[i] = F2{tanh_hw(h[i].x), tanh_hw(h[i].y)}; g[i] = b2[i]; }
+#pragma unroll
+    for (int k = 0; k < kPolicyHidden; ++k) {
+        const float hk = (k & 1) ? h[k / 2].y : h[k / 2].x;
+        const F2 xk = F2{hk, hk};
+#pragma unroll
+        for (int i = 0; i < H2; ++i) g[i] = __builtin_elementwise_fma(w2[k * H2 + i], xk, g[i]);
+    }
+    F2 acc = F2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < H2; ++i) acc = __builtin_elementwise_fma(w3[i], F2{tanh_hw(g[i].x), tanh_hw(g[i].y)}, acc);
+    const float a = (acc.x + acc.y) + b3[0];
+    return fminf(fmaxf(a, -1.0f), 1.0f);
+}
+
 // ---- kernels ------------------------------------------------------------------------------------------
 // ACAS2DEnv.step(), environment.py:29-42 -- and, with ROLLOUT, n_steps of them fused in one launch:
 // the state stays in registers, step t reads actions[t][E] and writes obs[t][E][D], reward[t][E],
 // done[t][E], outcome[t][E] (and the optional auto-reset side channels [t][E]...), finished envs
 // are reset on the fly (ROLLOUT implies AUTO_RESET semantics and a packed shape).  The per-step
 // arithmetic is this same code, so rollout(T) == T x step() bit for bit.
-template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT>
+// With POLICY (rollout, one lane per env) the action of every step comes from policy_action() on the
+// previous observation instead of from actions[t][E], which becomes an output.
+template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
-                                                      int tile_elems, int n_steps) {
+                                                      int tile_elems, int n_steps, PolicyW pw) {
     static_assert(!ROLLOUT || (AUTO_RESET && PACKED), "rollout: auto-reset semantics, packed shapes");
+    static_assert(!POLICY || (ROLLOUT && G == 1), "in-kernel policy: rollout mode, one lane per env");
     const Params<T> p = pinned(p_arg);
     constexpr int NS = PACKED ? C * G : 0;         // packed shapes: n_traffic is a compile-time constant
     const int N = PACKED ? NS : N_arg;
@@ -1059,7 +1123,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
 
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
     const int T_steps = ROLLOUT ? n_steps : 1;
-    T action_next = active ? io0.actions[el] : T(0);       // step t+1's action is fetched during step t
+    T action_next = T(0);                                  // step t+1's action is fetched during step t
+    if constexpr (POLICY) {
+        // the observation the first action is taken on (reset()'s / the previous step's) into the lane's row
+        const T* obs_in = static_cast<const T*>(pw.obs_in) + e_wave * D;
+        if (active) { for (int i = 0; i < D; ++i) row[i] = obs_in[el * D + i]; }
+    } else {
+        action_next = active ? io0.actions[el] : T(0);
+    }
     for (int t = 0; t < T_steps; ++t) {
         // outputs of step t: [t][E] / [t][E][D] slices (t == 0 for the per-step launch)
         const int64_t te = ROLLOUT ? (int64_t)t * n_envs : 0;
@@ -1069,8 +1140,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                            io0.ep_steps ? io0.ep_steps + te : nullptr};
         const bool last = !ROLLOUT || t == T_steps - 1;
         uint8_t oc = 0;
-        const T action = action_next;
-        if (ROLLOUT && active && t + 1 < T_steps) action_next = io.actions[n_envs + el];
+        T action = action_next;
+        if constexpr (POLICY) {
+            constexpr int DP = 5 + 3 * NS;                // compile-time obs width (packed shapes)
+            float x[DP];
+#pragma unroll
+            for (int i = 0; i < DP; ++i) x[i] = (float)row[i];
+            action = (T)policy_action<DP>(pw, x);
+            if (active) (static_cast<T*>(pw.actions_out) + e_wave + te)[el] = action;
+        } else {
+            if (ROLLOUT && active && t + 1 < T_steps) action_next = io.actions[n_envs + el];
+        }
         if (active) {
             if (t == 0) ACAS2D_STAMP(2, wave, lane, true);
 
@@ -1100,7 +1180,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
 
             // game.py:249-292 evaluate()
             T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
-            if constexpr (FAST) rw = rw * (T(1) - (T)steps * p.inv_max_steps);
+            if constexpr (FAST) rw = rw * m_fma(-(T)steps, p.inv_max_steps, T(1));
             else rw = rw * (T(1) - ((T)steps / (T)p.max_steps));              // :262-263
             const bool at_goal = r.d_goal < p.goal_radius;                    // :191-192
             if (r.collided) rw += p.reward_collision;                         // :279-280
@@ -1266,6 +1346,10 @@ int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStep
 template <typename T>
 int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, int32_t n_steps,
                    uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream);
+template <typename T>
+int launch_rollout_policy(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io,
+                          const Acas2dPolicy* pol, const void* obs_in, int32_t n_steps, uint64_t seed,
+                          int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream);
 template <typename T>
 int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* mask, void* obs,
                  int32_t do_init, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,

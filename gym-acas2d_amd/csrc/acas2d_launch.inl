@@ -80,10 +80,10 @@ static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, c
                        int64_t env_offset, int64_t n_envs, int N) {
     if (auto_reset)
         hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1);
+                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
     else
         hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1);
+                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
 }
 
 template <typename T, int C, int G>
@@ -91,7 +91,16 @@ static void rollout_shape(const Geometry& g, hipStream_t stream, const Params<T>
                           const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
                           int64_t n_envs, int N, int n_steps) {
     hipLaunchKernelGGL((step_kernel<T, C, G, true, true, kFast, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps);
+                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, PolicyW{});
+}
+
+// the same with the SB3 actor evaluated in the kernel (thread-per-env shapes only)
+template <typename T, int C>
+static void policy_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
+                         const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
+                         int64_t n_envs, int N, int n_steps, const PolicyW& pw) {
+    hipLaunchKernelGGL((step_kernel<T, C, 1, true, true, kFast, true, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, pw);
 }
 
 template <typename T, int C, int G, bool PACKED>
@@ -195,6 +204,45 @@ int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dS
     ACAS2D_PACKED_SHAPES(X)
 #undef X
     return check_launch("acas2d_rollout launch");
+}
+
+template <typename T>
+int launch_rollout_policy(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_,
+                          const Acas2dPolicy* pol, const void* obs_in, int32_t n_steps, uint64_t seed,
+                          int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
+    if (!cfg || !io_ || !pol) { set_error("acas2d_rollout_policy: NULL cfg / io / policy"); return ACAS2D_EINVAL; }
+    if (!state_complete(st)) { set_error("acas2d_rollout_policy: NULL state or a NULL state buffer"); return ACAS2D_EINVAL; }
+    if (!io_->actions || !io_->obs || !io_->reward || !io_->done || !io_->outcome || !obs_in) {
+        set_error("acas2d_rollout_policy: obs_in, actions (output), obs, reward, done and outcome are required"); return ACAS2D_EINVAL; }
+    if (!pol->w1t || !pol->b1 || !pol->w2t || !pol->b2 || !pol->w3 || !pol->b3 || pol->hidden != kPolicyHidden) {
+        set_error("acas2d_rollout_policy: six weight buffers and hidden == %d are required (got hidden = %d)", kPolicyHidden, pol->hidden);
+        return ACAS2D_EINVAL; }
+    if (n_traffic < 1 || n_steps < 1) { set_error("acas2d_rollout_policy: n_traffic = %d, n_steps = %d", n_traffic, n_steps); return ACAS2D_EINVAL; }
+    if (n_envs < 0 || env_offset < 0) { set_error("acas2d_rollout_policy: negative n_envs / env_offset"); return ACAS2D_EINVAL; }
+    if (n_envs == 0) return ACAS2D_OK;
+    const Shape sh{n_traffic, 1, true};                      // one lane per env, its traffic as one vector
+    bool ok = false;
+#define X(C_, G_) if (G_ == 1 && C_ == n_traffic) ok = true;
+    ACAS2D_PACKED_SHAPES(X)
+#undef X
+    if (!ok) {
+        set_error("acas2d_rollout_policy: n_traffic = %d has no thread-per-env shape for this element type", n_traffic);
+        return ACAS2D_EINVAL;
+    }
+    Geometry g;
+    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
+    const Params<T> p = make_params<T>(*cfg);
+    const ResetParams rp = make_reset_params<double>(*cfg);
+    const State<T> s = make_state<T>(*st);
+    const StepIO<T> io{(const T*)io_->actions, (T*)io_->obs, (T*)io_->reward, io_->done, io_->outcome,
+                       (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
+    const PolicyW pw{(const float*)pol->w1t, (const float*)pol->b1, (const float*)pol->w2t, (const float*)pol->b2,
+                     (const float*)pol->w3, (const float*)pol->b3, const_cast<void*>(io_->actions), obs_in};
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#define X(C_, G_) if constexpr (G_ == 1) { if (C_ == n_traffic) policy_shape<T, C_>(g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, n_steps, pw); }
+    ACAS2D_PACKED_SHAPES(X)
+#undef X
+    return check_launch("acas2d_rollout_policy launch");
 }
 
 template <typename T>

@@ -8,7 +8,7 @@ from .config import CConfig
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libacas2d_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 AUTO_RESET = 1
 
@@ -24,9 +24,15 @@ class CStepIO(C.Structure):
         "actions", "obs", "reward", "done", "outcome", "term_obs", "ep_return", "ep_steps")]
 
 
+class CPolicy(C.Structure):
+    """struct Acas2dPolicy: the SB3 MlpPolicy actor, float32, first two weights transposed."""
+    _fields_ = [(n, C.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "w3", "b3")] + \
+               [("hidden", C.c_int32), ("_pad", C.c_int32)]
+
+
 EXPORTS = ("acas2d_abi_version", "acas2d_config_size", "acas2d_last_error", "acas2d_step_f32",
-           "acas2d_step_f64", "acas2d_rollout_f32", "acas2d_rollout_f64", "acas2d_reset_f32",
-           "acas2d_reset_f64", "acas2d_launch_geometry")
+           "acas2d_step_f64", "acas2d_rollout_f32", "acas2d_rollout_f64", "acas2d_rollout_policy_f32",
+           "acas2d_rollout_policy_f64", "acas2d_reset_f32", "acas2d_reset_f64", "acas2d_launch_geometry")
 
 
 class NativeLibraryError(RuntimeError):
@@ -77,6 +83,11 @@ def lib():
         f.restype = C.c_int
         f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.POINTER(CStepIO), C.c_int32,
                       C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+    for name in ("acas2d_rollout_policy_f32", "acas2d_rollout_policy_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.POINTER(CStepIO), C.POINTER(CPolicy), C.c_void_p,
+                      C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
     for name in ("acas2d_reset_f32", "acas2d_reset_f64"):
         f = getattr(L, name)
         f.restype = C.c_int

@@ -41,6 +41,11 @@ class SB3ActorPolicy(torch.nn.Module):
         x = obs.to(torch.float32)
         return self.head(torch.tanh(self.l2(torch.tanh(self.l1(x)))))
 
+    def actor_weights(self):
+        """(w1 [64,D], b1, w2 [64,64], b2, w3 [1,64], b3) for ACAS2DVecEnv.rollout_policy()."""
+        return tuple(t.detach() for t in (self.l1.weight, self.l1.bias, self.l2.weight, self.l2.bias,
+                                          self.head.weight, self.head.bias))
+
     @torch.no_grad()
     def predict(self, obs, deterministic=True):
         """[E, obs_dim] -> [E, 1] float32 actions in [-1, 1] (deterministic = the mean action)."""

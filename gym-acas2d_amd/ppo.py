@@ -73,6 +73,12 @@ class ActorCritic(nn.Module):
         self.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()
                               if k in self.state_dict()}, strict=True)
 
+    def actor_weights(self):
+        """(w1 [64,D], b1, w2 [64,64], b2, w3 [1,64], b3) for ACAS2DVecEnv.rollout_policy()."""
+        pn = self.mlp_extractor.policy_net
+        return tuple(t.detach() for t in (pn[0].weight, pn[0].bias, pn[2].weight, pn[2].bias,
+                                          self.action_net.weight, self.action_net.bias))
+
     def forward(self, obs):
         x = obs.to(torch.float32)
         mean = self.action_net(self.mlp_extractor.policy_net(x))

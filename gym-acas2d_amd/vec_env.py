@@ -288,6 +288,50 @@ class ACAS2DVecEnv:
         out["_actions"] = a          # keep the (possibly re-laid-out) input alive until the launch ran
         return out
 
+    def rollout_policy(self, policy, n_steps, out=None, keep_terminal_obs=False):
+        """testing_main.py:69-105 in ONE kernel launch (acas2d_rollout_policy_*): for n_steps steps,
+        `action = policy.predict(obs, deterministic=True)` then `env.step(action)`, with the SB3
+        MlpPolicy actor (`policy.SB3ActorPolicy` / `ppo.ActorCritic`) evaluated inside the kernel on
+        the observation the previous step left -- `self.outputs["obs"]` at the start, so call
+        reset() / step() / set_state(observe=True) first.  One lane per env: n_traffic in
+        {1, 2, 3, 4, 8} for float32, {1, 2, 3} for float64.  Returns rollout()'s dict plus
+        "actions" [T, E] (the actions taken); VecEnv auto-reset semantics."""
+        if not self.auto_reset:
+            raise RuntimeError("rollout_policy() has VecEnv auto-reset semantics; construct with auto_reset=True")
+        T, E, D, dev = int(n_steps), self.num_envs, self.obs_dim, self.device
+        w = policy.actor_weights() if hasattr(policy, "actor_weights") else policy
+        w1, b1, w2, b2, w3, b3 = (torch.as_tensor(t, dtype=torch.float32).to(dev) for t in w)
+        if w1.shape != (64, D) or w2.shape != (64, 64) or w3.numel() != 64:
+            raise ValueError("policy must be the SB3 MlpPolicy actor %d -> 64 -> 64 -> 1, got %s %s %s"
+                             % (D, tuple(w1.shape), tuple(w2.shape), tuple(w3.shape)))
+        keep = [w1.t().contiguous(), b1.contiguous(), w2.t().contiguous(), b2.contiguous(),
+                w3.reshape(-1).contiguous(), b3.reshape(-1).contiguous()]
+        if out is None:
+            out = {"obs": torch.empty(T, E, D, dtype=self.dtype, device=dev),
+                   "actions": torch.empty(T, E, dtype=self.dtype, device=dev),
+                   "reward": torch.empty(T, E, dtype=self.dtype, device=dev),
+                   "done_u8": torch.empty(T, E, dtype=torch.uint8, device=dev),
+                   "outcome": torch.empty(T, E, dtype=torch.uint8, device=dev),
+                   "episode_return": torch.zeros(T, E, dtype=self.dtype, device=dev),
+                   "episode_steps": torch.zeros(T, E, dtype=torch.int32, device=dev),
+                   "terminal_observation": (torch.zeros(T, E, D, dtype=self.dtype, device=dev)
+                                            if keep_terminal_obs else None)}
+            out["done"] = out["done_u8"].view(torch.bool)
+        assert out["obs"].shape == (T, E, D) and out["actions"].shape == (T, E)
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        io = native.CStepIO(ptr(out["actions"]), ptr(out["obs"]), ptr(out["reward"]), ptr(out["done_u8"]),
+                            ptr(out["outcome"]), ptr(out.get("terminal_observation")), ptr(out["episode_return"]),
+                            ptr(out["episode_steps"]))
+        pol = native.CPolicy(*[ptr(t) for t in keep], 64, 0)
+        fn = (self._lib.acas2d_rollout_policy_f32 if self.dtype == torch.float32
+              else self._lib.acas2d_rollout_policy_f64)
+        with torch.cuda.device(dev):
+            native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), C.byref(pol), ptr(self._obs),
+                            T, self.seed_value, self.env_offset, E, self.n_traffic, self._stream()))
+            self._obs.copy_(out["obs"][T - 1])        # the observation the NEXT action would be taken on
+        out["_weights"] = keep       # keep the transposed copies alive until the launch ran
+        return out
+
     @property
     def actions_buffer(self):
         return self._actions

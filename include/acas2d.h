@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define ACAS2D_ABI_VERSION 1
+#define ACAS2D_ABI_VERSION 2
 
 /* error codes */
 #define ACAS2D_OK 0
@@ -149,6 +149,36 @@ int acas2d_rollout_f32(const Acas2dConfig *cfg, const Acas2dState *state, const 
 int acas2d_rollout_f64(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
                        int32_t n_steps, uint64_t seed, int64_t env_offset, int64_t n_envs,
                        int32_t n_traffic, void *stream);
+
+/*
+ * acas2d_rollout_policy_*: the rollout above with the policy evaluated INSIDE the kernel -- the
+ * whole loop of testing_main.py:69-105 (`action, _ = model.predict(obs, deterministic=True);
+ * obs, reward, done, info = env.step(action)`) in one launch.  The policy is Stable-Baselines3
+ * 1.1.0's MlpPolicy actor as stored in the reference's model zips (policy.pth:
+ * mlp_extractor.policy_net.{0,2}, action_net): obs -> Linear(D,64) tanh -> Linear(64,64) tanh ->
+ * Linear(64,1); the deterministic action is the mean clipped to [-1, 1].  float32 weights and
+ * float32 arithmetic in both element types (policy.predict() casts the observation to float32).
+ *   obs_in          T[E][D]  the observation the first action is taken on (reset()'s / the last step's)
+ *   io->actions     T[n_steps][E]  OUTPUT here: the action each step took
+ *   everything else as acas2d_rollout_*.
+ * Needs a thread-per-env work shape: n_traffic in {1, 2, 3, 4, 8} (f32) / {1, 2, 3} (f64).
+ */
+typedef struct Acas2dPolicy {
+    const void *w1t, *b1;    /* float[D][64]  = policy_net.0.weight TRANSPOSED, float[64] */
+    const void *w2t, *b2;    /* float[64][64] = policy_net.2.weight TRANSPOSED, float[64] */
+    const void *w3, *b3;     /* float[64]     = action_net.weight,              float[1]  */
+    int32_t hidden;          /* 64 */
+    int32_t _pad;
+} Acas2dPolicy;
+
+int acas2d_rollout_policy_f32(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
+                              const Acas2dPolicy *policy, const void *obs_in, int32_t n_steps,
+                              uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,
+                              void *stream);
+int acas2d_rollout_policy_f64(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
+                              const Acas2dPolicy *policy, const void *obs_in, int32_t n_steps,
+                              uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,
+                              void *stream);
 
 /*
  * acas2d_reset_*: replaces ACAS2DEnv.reset() (environment.py:44-48 -> ACAS2DGame.__init__,

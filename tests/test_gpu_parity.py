@@ -11,6 +11,8 @@ Tolerances (north star: masks bit-exact, 1e-5 abs on float positions / rewards):
       signed d_cpa entry), non-terminal rewards 1e-5 abs, positions / terminal rewards 1 float32
       ulp (1.3e-4); masks exact outside a 1e-3 band around the thresholds.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -543,6 +545,73 @@ def test_rollout_wraps_and_stores_injected_headings_like_steps(g, dtype_name):
     for name in ("own_psi", "trf_psi", "trf_x", "trf_y", "own_x", "own_y", "steps", "episode"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert float(a.trf_psi.max()) < 360.0 and float(a.own_psi.max()) < 360.0
+
+
+def _first_episode(out, E):
+    """outcome / game.steps / return of each env's FIRST finished episode in a rollout dict."""
+    done = out["done"].cpu().numpy()
+    assert done.any(0).all(), "every env must finish at least once"
+    t0 = done.argmax(0)
+    e = np.arange(E)
+    return (out["outcome"].cpu().numpy()[t0, e], out["episode_steps"].cpu().numpy()[t0, e],
+            out["episode_return"].cpu().numpy()[t0, e].astype(np.float64))
+
+
+def test_fused_policy_rollout_reproduces_the_reference_policy_evaluation(g):
+    """acas2d_rollout_policy_f64: testing_main.py's whole loop (policy.predict + env.step, 1001 steps,
+    100 episodes) in ONE launch with the reference's trained SB3 actor evaluated inside the kernel.
+    It must score what the reference recorded for that policy (mean return 1210.069219, mean length
+    704.35, 100/100 goals) -- the in-kernel float32 MLP differs from torch's by summation order
+    only (~1e-7 per action), so the table is held to 1e-4 relative instead of every digit."""
+    pol = g.load_sb3_policy(os.path.join(H.GOLDEN, "ref_policy_best_model.npz"), device="cuda:0")
+    own, trf, goal = H.parity_reset_states(g.ACAS2DConfig(), 13, 0, 100)
+    v = g.ACAS2DVecEnv(100, 1, device="cuda:0", dtype=torch.float64, auto_reset=True)
+    obs0 = v.set_state(own, trf, goal, np.zeros(100, np.int32), observe=True).clone()
+    out = v.rollout_policy(pol, 1001)
+    a0 = pol.predict(obs0).reshape(-1).to(torch.float64)
+    assert float((out["actions"][0] - a0).abs().max()) < 2e-6
+    oc, steps, ret = _first_episode(out, 100)
+    assert (oc == 1).all()
+    H.assert_matches_reference_policy_eval(ret, steps, 2.0 * (steps - 1), tol=1e-4)
+
+
+@pytest.mark.parametrize("N,E,T", ((1, 4096, 800), (3, 2048, 120), (8, 2048, 60)))
+def test_fused_policy_rollout_equals_policy_then_step(g, N, E, T):
+    """float32: the fused launch against torch's policy.predict() + step() per step on a twin env.
+    Same env arithmetic (bit-identical given the same actions); the two MLP evaluations differ by
+    rounding, so actions are compared to 1e-5 and the trajectories to a tolerance that allows that
+    difference to integrate -- and, where an env's actions happened to agree bit for bit all the
+    way, exactly."""
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    if N == 1:                                          # the reference's trained policy: reaches the goal
+        pol = g.load_sb3_policy(os.path.join(H.GOLDEN, "ref_policy_best_model.npz"), device=dev)
+    else:
+        pol = g.ActorCritic(5 + 3 * N).to(dev)
+        with torch.no_grad():                           # a policy that actually steers (the SB3 init is ~0)
+            pol.action_net.weight.mul_(60.0)
+    a = g.ACAS2DVecEnv(E, N, device=dev, dtype=torch.float32, seed=21)
+    b = g.ACAS2DVecEnv(E, N, device=dev, dtype=torch.float32, seed=21)
+    a.reset()
+    obs = b.reset().clone()
+    out = a.rollout_policy(pol, T)
+    same = torch.ones(E, dtype=torch.bool, device=dev)
+    worst_a = 0.0
+    for t in range(T):
+        act = pol.predict(obs).reshape(-1)
+        worst_a = max(worst_a, float((out["actions"][t] - act).abs().max()))
+        same &= out["actions"][t] == act
+        obs, rew, done, infos = b.step(out["actions"][t])          # feed the fused run's own actions
+        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew), t
+        assert torch.equal(out["done"][t], done) and torch.equal(out["outcome"][t], infos.outcome), t
+        obs = obs.clone()
+    assert worst_a < 1e-5, worst_a
+    assert float(out["actions"].abs().max()) > 0.2 and int(out["done"].sum()) > 0
+    for name in ("own_x", "own_y", "own_psi", "trf_x", "trf_y", "steps", "total_reward", "episode"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.outputs["obs"], b.outputs["obs"])
+    with pytest.raises(RuntimeError, match="thread-per-env"):
+        g.ACAS2DVecEnv(64, 16, device=dev).rollout_policy(g.ActorCritic(53).to(dev), 2)
 
 
 def test_lazy_infos_and_vecenv_surface(g):

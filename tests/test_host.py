@@ -69,12 +69,13 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol(g):
     header = open(os.path.join(ROOT, "include", "acas2d.h")).read()
     declared = set(re.findall(r"\b(acas2d_[a-z0-9_]+)\s*\(", header))
     assert {"acas2d_step_f32", "acas2d_step_f64", "acas2d_rollout_f32", "acas2d_rollout_f64",
+            "acas2d_rollout_policy_f32", "acas2d_rollout_policy_f64",
             "acas2d_reset_f32", "acas2d_reset_f64", "acas2d_last_error", "acas2d_abi_version"} <= declared
     L = g.native.lib()
     for name in declared:
         assert hasattr(L, name), name
     assert set(g.native.EXPORTS) == declared
-    assert L.acas2d_abi_version() == 1 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
+    assert L.acas2d_abi_version() == g.native.ABI_VERSION == 2 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
     assert int(re.search(r"#define ACAS2D_ABI_VERSION (\d+)", header).group(1)) == g.native.ABI_VERSION
 
 
