@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Fused policy rollout (acas2d_rollout_policy_*) beside torch policy.predict() + step():
+(1) the reference's recorded policy evaluation from the fused float64 launch, (2) env-steps/s of both
+ways at E envs x N_TRAFFIC=1, float32.  usage: bench_policy_rollout.py [E]"""
 import os, sys, time, json, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,8 +17,8 @@ out = v.rollout_policy(pol, 1001)
 done = out["done"].cpu().numpy(); t0 = done.argmax(0); e = np.arange(100)
 ret = out["episode_return"].cpu().numpy()[t0, e]; st = out["episode_steps"].cpu().numpy()[t0, e]
 d = H.describe(ret); res["f64_fused_table"] = {k: round(float(x), 6) for k, x in d.items()}; res["f64_steps_mean"] = float(st.mean())
-# 2. throughput: fused policy rollout vs torch policy + step per step, 65536 envs x N=1, f32
-E, T = 65536, 200
+# 2. throughput: fused policy rollout vs torch policy + step per step, E envs x N=1, f32
+E, T = int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 200
 a = g.ACAS2DVecEnv(E, 1, device=dev, dtype=torch.float32, seed=13); a.reset()
 o = a.rollout_policy(pol, T)
 torch.cuda.synchronize()
