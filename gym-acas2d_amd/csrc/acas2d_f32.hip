@@ -1,4 +1,6 @@
-// float32 instantiation (throughput mode, FAST formulation).  Built with -ffp-contract=fast.
+// float32 instantiation (throughput mode, FAST formulation).  Built with -ffp-contract=off like the
+// float64 one: only the fma()s written in the source fuse, so every instantiation (work shape, rollout,
+// policy variant) rounds alike -- measured free (7.13 us either way at 65 536 x 8).
 #define ACAS2D_PACKED_SHAPES(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(8, 1) X(4, 2) X(2, 4) X(4, 4) X(4, 8) X(4, 16) X(8, 8) X(2, 32)
 namespace acas2d {
 constexpr bool kFast = true;

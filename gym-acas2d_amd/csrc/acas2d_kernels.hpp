@@ -285,9 +285,10 @@ template <typename T, bool FAST>
 __device__ __forceinline__ T step_reward_5(const Params<T>& p, T v_closing, T psi, T phi, T d_cpa,
                                             T d_goal, T d_dev) {
     if constexpr (FAST) {
-        // every 1 - a*b below is an EXPLICIT fma: left to -ffp-contract=fast, different instantiations
-        // of the kernel (work shapes, rollout / policy variants) fused some of them and not others,
-        // and the same state gave rewards one ulp apart depending on the shape that stepped it
+        // every 1 - a*b below is an EXPLICIT fma.  (Under -ffp-contract=fast, which this build used to
+        // have, different instantiations of the kernel -- work shapes, rollout / policy variants --
+        // fused some of them and not others, and the same state gave rewards one ulp apart depending
+        // on the shape that stepped it; the build is -ffp-contract=off now, belt and braces.)
         T hr = pow4(m_fma(-delta_heading(psi, phi), T(1.0 / 180.0), T(1)));
         if (v_closing <= T(0)) {
             T car = py_min1(pow4(d_cpa * p.inv_safe_distance));
@@ -369,7 +370,7 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 }
 __device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
 __device__ __forceinline__ double uniform(double a, double b, double u) {
-#pragma clang fp contract(off)   // same rounding in the f32 (contract=fast) and f64 builds
+#pragma clang fp contract(off)   // same rounding in both builds whatever their -ffp-contract
     return a + (b - a) * u;
 }
 // float32 build, in-step reset only: the same draws evaluated in float32 (24 random bits per
@@ -388,9 +389,9 @@ template <typename T, int W>
 __device__ __forceinline__ void store_chunk(Vec<T, W>* dst, const Vec<T, W>& v);
 
 // ---- one env's player, as every lane of its group sees it ------------------------------------------
-// A product rounded to T that the compiler can no longer contract into an fma (hipcc's default
-// -ffp-contract=fast lets the backend fuse across statements, whatever a pragma says; an empty asm
-// is the one thing it cannot see through).  The reference's differences of such products --
+// A product rounded to T that the compiler can never contract into an fma, whatever the build's
+// -ffp-contract setting (fast lets the backend fuse across statements whatever a pragma says; an
+// empty asm is the one thing it cannot see through).  The reference's differences of such products --
 // relative velocity v1 cos(psi1) - v2 cos(psi2) (kinematics.py:35-36), the velocity difference of
 // the closing speed (:70-76) -- cancel to EXACTLY 0 in parallel flight: 0/0 -> NaN d_cpa, closing
 // speed 0 -> the `v_closing <= 0` reward branch.  An fma keeps one product unrounded and leaves a

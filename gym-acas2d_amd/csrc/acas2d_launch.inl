@@ -1,8 +1,8 @@
 // acas2d_launch.inl -- host-side launchers, included by acas2d_f32.hip and acas2d_f64.hip which
 // define ACAS2D_PACKED_SHAPES(X) (the (C, G) pairs to instantiate for their element type) and
-// kFast, then instantiate launch_step<T> / launch_reset<T>.  (Two translation units so that the
-// float64 parity build can be compiled with -ffp-contract=off while the float32 throughput build
-// keeps fused multiply-adds.)
+// kFast, then instantiate launch_step<T> / launch_reset<T>.  (Two translation units: each element
+// type is compiled with its own flags.  Both use -ffp-contract=off today, so only the fma()s written
+// in the source fuse.)
 #include <stdlib.h>
 
 #include "acas2d_kernels.hpp"
