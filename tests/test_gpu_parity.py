@@ -547,6 +547,41 @@ def test_rollout_wraps_and_stores_injected_headings_like_steps(g, dtype_name):
     assert float(a.trf_psi.max()) < 360.0 and float(a.own_psi.max()) < 360.0
 
 
+@pytest.mark.parametrize("dtype_name,N,shapes", (
+    ("float32", 8, ("4,2", "8,1", "2,4", "generic,4", "generic,1")),
+    ("float32", 64, ("4,16", "8,8", "2,32", "generic,16", "generic,64")),
+    ("float64", 8, ("2,4", "4,2", "generic,4"))))
+def test_results_do_not_depend_on_the_work_shape(g, dtype_name, N, shapes):
+    """How the traffic of an env is spread over lanes (ACAS2D_SHAPE, a tuning knob) must not change a
+    single bit: both builds compile with -ffp-contract=off, every variant runs the same IEEE
+    operations per aircraft (packed float2 math included), and the reset RNG is keyed per entity."""
+    dtype = getattr(torch, dtype_name)
+    E, T = 1536, 120
+    gen = torch.Generator(device="cuda:0").manual_seed(4)
+    actions = torch.rand(T, E, generator=gen, device="cuda:0", dtype=dtype) * 2 - 1
+    ref = None
+    try:
+        for sh in shapes:
+            os.environ["ACAS2D_SHAPE"] = sh
+            v = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=8)
+            assert g.native.launch_geometry(E, N, 4 if dtype == torch.float32 else 8)["lanes_per_env"] == int(sh.split(",")[1])
+            got = [v.reset().clone()]
+            dones = 0
+            for t in range(T):
+                obs, rew, done, infos = v.step(actions[t])
+                got += [obs.clone(), rew.clone(), done.clone(), infos.outcome.clone()]
+                dones += int(done.sum())
+            got += [v.trf_x.clone(), v.trf_psi.clone(), v.own_psi.clone(), v.total_reward.clone(), v.episode.clone()]
+            assert dones > 0
+            if ref is None:
+                ref = got
+            else:
+                for k, (a, b) in enumerate(zip(ref, got)):
+                    assert torch.equal(a, b), (sh, k)
+    finally:
+        os.environ.pop("ACAS2D_SHAPE", None)
+
+
 def _first_episode(out, E):
     """outcome / game.steps / return of each env's FIRST finished episode in a rollout dict."""
     done = out["done"].cpu().numpy()
