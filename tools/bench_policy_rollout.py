@@ -6,6 +6,8 @@ import os, sys, time, json, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gym_acas2d_amd as g, helpers as H
+if os.environ.get("ACAS2D_BENCH_LIB"):            # diagnostic builds
+    g.native.LIB_PATH = os.path.join(ROOT, "gym-acas2d_amd", "csrc", os.environ["ACAS2D_BENCH_LIB"])
 dev = "cuda:0"
 pol = g.load_sb3_policy(os.path.join(H.GOLDEN, "ref_policy_best_model.npz"), device=dev)
 res = {}
