@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--rollout-steps", type=int, default=200)
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic: latch outcomes instead of resetting")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-collisions", action="store_true",
+                    help="diagnostic (SURVEY.md 8d, C4): collision distance 0, so episodes end at the goal / by "
+                         "timeout only and resets are rare -- isolates the step itself at large N_TRAFFIC")
     return ap.parse_args()
 
 
@@ -112,6 +115,8 @@ def main():
 
     env = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13, env_offset=rank * E,
                          auto_reset=not args.no_auto_reset)
+    if args.no_collisions:
+        env._ccfg.collision_dist = 0.0
     env.reset()
     chunk = max(1, min(args.chunk, K))
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -209,7 +214,9 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "%d envs x N_TRAFFIC=%d per GPU, %s, one step-kernel launch per step(), "
-                                   "auto-reset on, random actions U(-1,1)" % (E, N, args.dtype),
+                                   "auto-reset %s, random actions U(-1,1)%s"
+                                   % (E, N, args.dtype, "off" if args.no_auto_reset else "on",
+                                      ", collisions disabled (diagnostic)" if args.no_collisions else ""),
                        "envs_per_gpu": E, "n_traffic": N, "launch": args.launch,
                        "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"],
                        "grid_blocks": geo["grid_blocks"],
