@@ -285,6 +285,7 @@ class ACAS2DVecEnv:
         with torch.cuda.device(dev):
             native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), T, self.seed_value,
                             self.env_offset, E, self.n_traffic, self._stream()))
+            self._obs.copy_(out["obs"][T - 1])        # outputs["obs"] stays "the latest observation"
         out["_actions"] = a          # keep the (possibly re-laid-out) input alive until the launch ran
         return out
 

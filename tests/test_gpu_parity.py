@@ -510,6 +510,7 @@ def test_rollout_equals_sequential_steps(g, dtype_name, N, E, T):
     for name in ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi", "trf_v",
                  "steps", "total_reward", "episode"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.outputs["obs"], b.outputs["obs"])          # the latest observation, either way
     # and a second rollout continues from the state the first one left, reusing the buffers
     actions2 = torch.rand(T, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
     out = a.rollout(actions2, out=out)
