@@ -760,6 +760,33 @@ def test_linearity_of_motion_at_one_million_envs(g):
     assert int(live.sum()) > 0
 
 
+def test_plain_cpp_host_program_on_the_c_abi_matches_the_python_host(g):
+    """examples/c_abi_example.cpp: hipMalloc + acas2d_reset_f32 + acas2d_step_f32 from C++, no Python
+    and no torch in the process.  Same seed, same constant action 0, auto-reset: it must count the same
+    finished episodes and end on the same observations as ACAS2DVecEnv."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_abi_example")
+    subprocess.run(["make", "-C", os.path.join(root, "gym-acas2d_amd", "csrc"), "example"], check=True,
+                   capture_output=True)
+    E, N, T = 3000, 3, 450
+    out = subprocess.run([exe, str(E), str(N), str(T)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(out[0]), int(out[1]), int(out[2])] == [E, N, T]
+    v = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, seed=13)
+    v.reset()
+    zero = torch.zeros(E, device="cuda:0")
+    finished, reward_sum = 0, 0.0
+    for _ in range(T):
+        obs, rew, done, _ = v.step(zero)
+        finished += int(done.sum())
+        reward_sum += float(rew.double().sum())
+    w = (1 + torch.arange(obs.numel(), device="cuda:0") % 7).double()
+    checksum = float((obs.reshape(-1).double() * w).sum())
+    assert finished > 0 and int(out[3]) == finished
+    assert abs(float(out[4]) - reward_sum) <= 1e-9 * abs(reward_sum)
+    assert abs(float(out[5]) - checksum) <= 1e-9 * abs(checksum)
+
+
 def test_c_abi_rejects_bad_arguments_on_gpu_box(g):
     import ctypes as C
     L = g.native.lib()
