@@ -91,3 +91,27 @@ def evaluate_policy(venv, policy, max_steps=None):
     return {"outcome": outcome.cpu().numpy(), "steps": steps_np,
             "total_reward": ret.cpu().numpy().astype(np.float64),
             "path_length": step_len * (steps_np - 1), "unfinished": int(active.sum().item())}
+
+
+def evaluate_policy_fused(policy, own, traffic, goal=None, dtype=torch.float64, device="cuda:0", config=None,
+                          max_steps=None):
+    """evaluate_policy() as ONE kernel launch (ACAS2DVecEnv.rollout_policy): the episodes given by
+    `own` [E,4] / `traffic` [E,N,4] / `goal` are run with the deterministic SB3 actor evaluated inside
+    the rollout kernel; results are those of each env's FIRST episode (the launch has VecEnv
+    auto-reset semantics and keeps stepping the envs that finish early).  Thread-per-env shapes only
+    (N in {1,2,3,4,8} float32, {1,2,3} float64)."""
+    from .vec_env import ACAS2DVecEnv
+    own, traffic = np.asarray(own), np.asarray(traffic)
+    E, N = own.shape[0], traffic.shape[1]
+    v = ACAS2DVecEnv(E, N, device=device, dtype=dtype, auto_reset=True, config=config)
+    v.set_state(own, traffic, goal, np.zeros(E, np.int32), observe=True)
+    T = (max_steps or v.config.max_steps) + 1
+    out = v.rollout_policy(policy, T)
+    done = out["done"].cpu().numpy()
+    fin = done.any(0)
+    t0, e = done.argmax(0), np.arange(E)
+    steps = np.where(fin, out["episode_steps"].cpu().numpy()[t0, e], 0)
+    step_len = v.config.airspeed * v.config.dt
+    return {"outcome": np.where(fin, out["outcome"].cpu().numpy()[t0, e], 0).astype(np.uint8), "steps": steps,
+            "total_reward": np.where(fin, out["episode_return"].cpu().numpy()[t0, e], 0.0).astype(np.float64),
+            "path_length": step_len * (steps - 1), "unfinished": int((~fin).sum())}

@@ -609,6 +609,15 @@ def test_fused_policy_rollout_reproduces_the_reference_policy_evaluation(g):
     oc, steps, ret = _first_episode(out, 100)
     assert (oc == 1).all()
     H.assert_matches_reference_policy_eval(ret, steps, 2.0 * (steps - 1), tol=1e-4)
+    # the convenience wrapper, and the step-by-step evaluation it replaces
+    fused = g.evaluate_policy_fused(pol, own, trf, goal)
+    assert fused["unfinished"] == 0 and np.array_equal(fused["outcome"], oc) and np.array_equal(fused["steps"], steps)
+    ev = g.ACAS2DVecEnv(100, 1, device="cuda:0", dtype=torch.float64, auto_reset=False)
+    ev.set_state(own, trf, goal, np.zeros(100, np.int32))
+    slow = g.evaluate_policy(ev, pol)
+    assert np.array_equal(slow["outcome"], fused["outcome"]) and np.array_equal(slow["steps"], fused["steps"])
+    assert np.abs(slow["total_reward"] - fused["total_reward"]).max() < 1e-3
+    np.testing.assert_allclose(slow["path_length"], fused["path_length"])
 
 
 @pytest.mark.parametrize("N,E,T", ((1, 4096, 800), (3, 2048, 120), (8, 2048, 60)))

@@ -31,9 +31,7 @@ hist = trainer.learn(int(args.timesteps), log=lambda r: print(json.dumps(r), flu
 if args.traffic == 1:
     import helpers as H
     own, trf, goal = H.parity_reset_states(g.ACAS2DConfig(), 13, 0, 100)
-    ev = g.ACAS2DVecEnv(100, 1, device="cuda:0", dtype=torch.float64, auto_reset=False)
-    ev.set_state(own, trf, goal, np.zeros(100, np.int32))
-    out = g.evaluate_policy(ev, trainer.policy)
+    out = g.evaluate_policy_fused(trainer.policy, own, trf, goal)     # predict + step x 1001 in one launch
     print(json.dumps({"eval_100_reference_episodes": {"mean_return": float(out["total_reward"].mean()),
                                                       "mean_steps": float(out["steps"].mean()),
                                                       "goal": int((out["outcome"] == 1).sum()),
