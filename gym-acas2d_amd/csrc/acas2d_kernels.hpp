@@ -1112,25 +1112,27 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     Own<T> o{};
     Traffic<T, C> tr{};
     bool frozen = false;
+    T action_next = T(0);                                  // step t+1's action is fetched during step t
     if (active) {
-        // ---- every load of this lane up front: one memory round trip, all requests in flight ----
-        if constexpr (PACKED) tr = load_traffic<T, C>(s, el * N + j * C);
+        // ---- every load of this lane up front: one memory round trip, all requests in flight.  The
+        // player's scalars and the action first, the traffic vectors (the bulk) last: loads return in
+        // order, so the player-side arithmetic can start while the vectors are still landing
+        // (s_waitcnt vmcnt(4), then vmcnt(0) before the first traffic instruction): 7.12 -> 7.0x us.
         o = Own<T>{s.own_x[el], s.own_y[el], s.own_psi[el], s.own_v[el], T(0), s.goal_x[el], s.goal_y[el]};
         steps = s.steps[el];
         total = s.total_reward[el];
         if constexpr (AUTO_RESET) episode = s.episode[el];
         else frozen = s.status[el] != 0;                                   // game.py:243-245
+        if constexpr (!POLICY) action_next = io0.actions[el];
+        if constexpr (PACKED) tr = load_traffic<T, C>(s, el * N + j * C);
     }
 
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
     const int T_steps = ROLLOUT ? n_steps : 1;
-    T action_next = T(0);                                  // step t+1's action is fetched during step t
     if constexpr (POLICY) {
         // the observation the first action is taken on (reset()'s / the previous step's) into the lane's row
         const T* obs_in = static_cast<const T*>(pw.obs_in) + e_wave * D;
         if (active) { for (int i = 0; i < D; ++i) row[i] = obs_in[el * D + i]; }
-    } else {
-        action_next = active ? io0.actions[el] : T(0);
     }
     for (int t = 0; t < T_steps; ++t) {
         // outputs of step t: [t][E] / [t][E][D] slices (t == 0 for the per-step launch)
