@@ -618,10 +618,11 @@ template <typename T, int C>
 __device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int i0) {
     using V = Vec<T, C>;
     Traffic<T, C> t;
-    t.x = *reinterpret_cast<const V*>(s.trf_x + i0);
-    t.y = *reinterpret_cast<const V*>(s.trf_y + i0);
+    // headings and speeds first: sin / cos and v dt start while the positions are still landing
     t.psi = *reinterpret_cast<const V*>(s.trf_psi + i0);
     t.v = *reinterpret_cast<const V*>(s.trf_v + i0);
+    t.x = *reinterpret_cast<const V*>(s.trf_x + i0);
+    t.y = *reinterpret_cast<const V*>(s.trf_y + i0);
     return t;
 }
 
