@@ -991,6 +991,34 @@ __device__ __forceinline__ void flush_tile(const T* __restrict__ tile, T* __rest
     }
 }
 
+// flush_tile() with the trip count known at compile time (packed shapes: at most CHUNKS 16-byte
+// chunks per lane): ALL LDS reads are issued before the first store.  The rolled loop above reads,
+// waits for LDS, stores, and only then reads the next chunk -- four LDS round trips back to back at
+// the very end of every wave.
+template <typename T, int CHUNKS>
+__device__ __forceinline__ void flush_tile_unrolled(const T* __restrict__ tile, T* __restrict__ dst, int count,
+                                                    int lane) {
+    constexpr int W = 16 / sizeof(T);
+    using V = Vec<T, W>;
+    if (__builtin_expect((reinterpret_cast<uintptr_t>(dst) & 15u) == 0, 1)) {
+        const int nv = count / W;
+        V buf[CHUNKS];
+#pragma unroll
+        for (int u = 0; u < CHUNKS; ++u) {
+            const int i = lane + 64 * u;
+            if (i < nv) buf[u] = reinterpret_cast<const V*>(tile)[i];
+        }
+#pragma unroll
+        for (int u = 0; u < CHUNKS; ++u) {
+            const int i = lane + 64 * u;
+            if (i < nv) store_chunk<T, W>(reinterpret_cast<V*>(dst) + i, buf[u]);
+        }
+        for (int i = nv * W + lane; i < count; i += 64) dst[i] = tile[i];
+    } else {
+        for (int i = lane; i < count; i += 64) dst[i] = tile[i];
+    }
+}
+
 // Re-flush the values [first, last) of the tile (one env's row after its reset) with exactly the
 // chunk -> lane mapping of flush_tile().
 template <typename T>
@@ -1114,18 +1142,25 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     Traffic<T, C> tr{};
     bool frozen = false;
     T action_next = T(0);                                  // step t+1's action is fetched during step t
-    if (active) {
+    // Packed shapes run loads and arithmetic on EVERY lane of the wave -- the lanes past the last env
+    // (last wave only) on a copy of the wave's first env -- and predicate only the stores.  With the
+    // loads and their first uses inside `if (active)`, the compiler's waitcnt model kept them pending
+    // on the path around it and, vmcnt retiring in order, made every later loop and LDS read of the
+    // kernel wait for all stores issued in between (s_waitcnt vmcnt(0) before the tile flush).
+    const bool run = PACKED ? true : active;
+    const int el_l = (PACKED && !active) ? 0 : el;         // the env a lane LOADS
+    if (run) {
         // ---- every load of this lane up front: one memory round trip, all requests in flight.  The
         // player's scalars and the action first, the traffic vectors (the bulk) last: loads return in
         // order, so the player-side arithmetic can start while the vectors are still landing
         // (s_waitcnt vmcnt(4), then vmcnt(0) before the first traffic instruction): 7.12 -> 7.0x us.
-        o = Own<T>{s.own_x[el], s.own_y[el], s.own_psi[el], s.own_v[el], T(0), s.goal_x[el], s.goal_y[el]};
-        steps = s.steps[el];
-        total = s.total_reward[el];
-        if constexpr (AUTO_RESET) episode = s.episode[el];
-        else frozen = s.status[el] != 0;                                   // game.py:243-245
-        if constexpr (!POLICY) action_next = io0.actions[el];
-        if constexpr (PACKED) tr = load_traffic<T, C>(s, el * N + j * C);
+        o = Own<T>{s.own_x[el_l], s.own_y[el_l], s.own_psi[el_l], s.own_v[el_l], T(0), s.goal_x[el_l], s.goal_y[el_l]};
+        steps = s.steps[el_l];
+        total = s.total_reward[el_l];
+        if constexpr (AUTO_RESET) episode = s.episode[el_l];
+        else frozen = s.status[el_l] != 0;                                 // game.py:243-245
+        if constexpr (!POLICY) action_next = io0.actions[el_l];
+        if constexpr (PACKED) tr = load_traffic<T, C>(s, el_l * N + j * C);
     }
 
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
@@ -1155,7 +1190,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         } else {
             if (ROLLOUT && active && t + 1 < T_steps) action_next = io.actions[n_envs + el];
         }
-        if (active) {
+        if (run) {
             if (t == 0) ACAS2D_STAMP(2, wave, lane, true);
 
             // game.py:225 + aircraft.py:16-26 for the player
@@ -1179,7 +1214,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // `episode` is first USED in the reset loop far below; without this use the compiler waits
             // for its load there with s_waitcnt vmcnt(0) -- i.e. for every store issued since.
             asm volatile("" : "+v"(episode));
-            Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last,
+            Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
                                                        ROLLOUT ? &trig : nullptr);
 
             // game.py:249-292 evaluate()
@@ -1192,11 +1227,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // game.py:294-314 is_done(): timeout > collision > goal
             oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
             total = total + rw;                                               // :287
+            if (!active) oc = 0;                          // a padding lane never finishes anything
 #if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 4
             asm volatile("" :: "v"(rw), "v"(o.x), "v"(o.y), "v"(o.psi));
             if (false) {
 #else
-            if (j == 0) {
+            if (j == 0 && active) {
 #endif
                 io.reward[el] = rw;
                 io.done[el] = oc != 0;
@@ -1272,7 +1308,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         // Flush the tile (generic walk: now, the stores drain while finished envs are reset below).
         wave_lds_fence();
 #if !defined(ACAS2D_ABLATE) || ACAS2D_ABLATE < 2
-        flush_tile<T>(tile, obs_wave, n_rows * D, lane);
+        if constexpr (PACKED) {
+            constexpr int kChunks = (EPW * (5 + 3 * NS) * (int)sizeof(T) / 16 + 63) / 64;
+            flush_tile_unrolled<T, kChunks>(tile, obs_wave, n_rows * D, lane);
+        } else {
+            flush_tile<T>(tile, obs_wave, n_rows * D, lane);
+        }
 #endif
         if (t == 0) ACAS2D_STAMP(4, wave, lane, false);
         if constexpr (AUTO_RESET && !HANDOFF) {
