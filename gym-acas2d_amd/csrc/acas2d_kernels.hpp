@@ -638,6 +638,9 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
                                            Traffic<T, C>& tr, T* __restrict__ row, bool store_traffic = true,
                                            TrigCache<T, C>* tc = nullptr) {
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
+    // Keep the traffic arithmetic below this line: the player side above needs only the scalars, which
+    // were requested first, so it runs under s_waitcnt vmcnt(11..5) while the traffic vectors land.
+    if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
     Seen<T> r;
     r.d_goal = c.d_goal; r.h_goal = c.h_goal; r.d_dev = c.d_dev;
     int coll = 0;
