@@ -25,7 +25,7 @@ def counter(name, E):
     vals = []
     for f in glob.glob(os.path.join(d, "pmc_%s_%d" % (name, E), "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "step_kernel" in r["Kernel_Name"] and "true, false>" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            if "step_kernel" in r["Kernel_Name"] and "true, false, false>" in r["Kernel_Name"] and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"]))
     vals = vals[len(vals) // 4:]
     return statistics.mean(vals) if vals else None
