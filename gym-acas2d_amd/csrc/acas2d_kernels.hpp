@@ -1114,10 +1114,19 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                                                       int tile_elems, int n_steps, PolicyW pw) {
     static_assert(!ROLLOUT || (AUTO_RESET && PACKED), "rollout: auto-reset semantics, packed shapes");
     static_assert(!POLICY || (ROLLOUT && G == 1), "in-kernel policy: rollout mode, one lane per env");
-    const Params<T> p = pinned(p_arg);
     constexpr int NS = PACKED ? C * G : 0;         // packed shapes: n_traffic is a compile-time constant
     const int N = PACKED ? NS : N_arg;
     constexpr int EPW = 64 / G;                    // envs per wavefront
+    // Everything the loads below need from the kernel arguments, requested in ONE scalar-load round
+    // trip: left alone, hipcc fetches the grid size, then n_envs (early exit), then the pointers, each
+    // behind its own s_waitcnt -- three dependent round trips before the first global load.
+    {
+        const uint32_t nb = gridDim.x;
+        asm volatile("" :: "s"(nb), "s"(n_envs), "s"(s_arg.own_x), "s"(s_arg.own_y), "s"(s_arg.own_psi), "s"(s_arg.own_v),
+                     "s"(s_arg.goal_x), "s"(s_arg.goal_y), "s"(s_arg.trf_x), "s"(s_arg.trf_y), "s"(s_arg.trf_psi),
+                     "s"(s_arg.trf_v), "s"(s_arg.steps), "s"(s_arg.total_reward), "s"(s_arg.episode), "s"(io_arg.actions),
+                     "s"(tile_elems));
+    }
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
     const int wib = wave_in_block();
@@ -1166,6 +1175,18 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         if constexpr (PACKED) tr = load_traffic<T, C>(s, el_l * N + j * C);
     }
 
+    // Launch constants into VGPRs only now, AFTER the loads are in flight: pinned() is ~25 v_movs
+    // behind a kernarg s_load round trip, which used to sit in front of the first global load.
+    const Params<T> p = pinned(p_arg);
+    if constexpr (AUTO_RESET && !ROLLOUT) {
+        // ... and what the reset of a finished env reads, so that its wave does not start the reset
+        // with a scalar-load round trip (the kernel ends with that wave)
+        asm volatile("" :: "s"(rp.own_x0), "s"(rp.own_y0), "s"(rp.own_v), "s"(rp.own_heading0), "s"(rp.own_heading_jitter),
+                     "s"(rp.goal_x), "s"(rp.goal_y), "s"(rp.t0_x), "s"(rp.t0_y_base), "s"(rp.t0_y_span),
+                     "s"(rp.t0_heading_base), "s"(rp.t0_heading_step), "s"(rp.t0_heading_jitter), "s"(rp.tn_x_max),
+                     "s"(rp.tn_y_max), "s"(rp.speed_factor_min), "s"(rp.speed_factor_max), "s"(rp.airspeed),
+                     "s"(k0), "s"(k1), "s"(io_arg.ep_steps));
+    }
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
     const int T_steps = ROLLOUT ? n_steps : 1;
     if constexpr (POLICY) {
