@@ -310,16 +310,37 @@ __device__ __forceinline__ T step_reward_5(const Params<T>& p, T v_closing, T ps
 }
 
 // ---- cross-lane helpers within a group of G lanes ------------------------------------------------
+// Groups of 2 or 4 lanes sit inside a DPP quad: the exchange is one v_mov_b32 with a quad_perm
+// modifier (no LDS crossbar round trip as with ds_bpermute, which cost the headline (4,2) shape
+// three lgkmcnt waits in the middle of its arithmetic).  quad_perm [a,b,c,d] = a | b<<2 | c<<4 | d<<6.
+template <int CTRL>
+__device__ __forceinline__ int quad_perm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
 template <int G>
 __device__ __forceinline__ int group_or(int v) {
+    if constexpr (G == 2) return v | quad_perm<0xB1>(v);                      // [1,0,3,2]
+    else if constexpr (G == 4) { v |= quad_perm<0xB1>(v); return v | quad_perm<0x4E>(v); }   // then [2,3,0,1]
+    else {
 #pragma unroll
-    for (int m = 1; m < G; m <<= 1) v |= __shfl_xor(v, m, 64);
-    return v;
+        for (int m = 1; m < G; m <<= 1) v |= __shfl_xor(v, m, 64);
+        return v;
+    }
 }
-template <int G, typename T>
-__device__ __forceinline__ T group_bcast0(T v) {
+template <int G>
+__device__ __forceinline__ float group_bcast0(float v) {
     if constexpr (G == 1) return v;
-    return __shfl(v, (int)(threadIdx.x & 63u) & ~(G - 1), 64);
+    else if constexpr (G == 2) return __int_as_float(quad_perm<0xA0>(__float_as_int(v)));     // [0,0,2,2]
+    else if constexpr (G == 4) return __int_as_float(quad_perm<0x00>(__float_as_int(v)));     // [0,0,0,0]
+    else return __shfl(v, (int)(threadIdx.x & 63u) & ~(G - 1), 64);
+}
+template <int G>
+__device__ __forceinline__ double group_bcast0(double v) {
+    if constexpr (G == 1) return v;
+    else if constexpr (G == 2 || G == 4) {
+        constexpr int CTRL = G == 2 ? 0xA0 : 0x00;
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = (unsigned)quad_perm<CTRL>((int)(unsigned)b), hi = (unsigned)quad_perm<CTRL>((int)(unsigned)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    } else return __shfl(v, (int)(threadIdx.x & 63u) & ~(G - 1), 64);
 }
 
 // Value of `v` in lane `src` (wave-uniform, so a v_readlane instead of a ds_bpermute round trip).
