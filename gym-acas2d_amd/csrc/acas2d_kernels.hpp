@@ -902,10 +902,13 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
     const int64_t wave_dbg = remap_block() * kWavesPerBlock + (threadIdx.x >> 6);
 #endif
     ACAS2D_STAMP(8, wave_dbg, lane, false);
-    if (io.term_obs) {                                   // the finished episode's last observation
-        T* t_row = io.term_obs + e * D;
-        if constexpr (NS > 0 && 5 + 3 * NS <= 64) { if (lane < D) t_row[lane] = row[lane]; }
-        else { for (int i = lane; i < D; i += 64) t_row[i] = row[i]; }
+    // The finished episode's last observation: read from the row now, stored after the Philox block
+    // (the LDS round trip of the read then hides under it instead of standing in front of it).
+    constexpr bool kOneTermPass = NS > 0 && 5 + 3 * NS <= 64;
+    T term_v = T(0);
+    if (io.term_obs) {
+        if constexpr (kOneTermPass) { if (lane < D) term_v = row[lane]; }
+        else { T* t_row = io.term_obs + e * D; for (int i = lane; i < D; i += 64) t_row[i] = row[i]; }
     }
     const uint32_t episode = episode_prev + 1u;
     wave_lds_fence();                                    // row reads precede its rewrite below
@@ -940,6 +943,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
         }
     }
     ACAS2D_STAMP(9, wave_dbg, lane, false);
+    if constexpr (kOneTermPass) { if (io.term_obs && lane < D) (io.term_obs + e * D)[lane] = term_v; }
     psi_own = lane_value(psi_own, 0);
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
