@@ -294,6 +294,11 @@ int64_t acas2d_oracle_step(const Acas2dOracleConfig *cfg, const Acas2dOracleStat
 {
     const int32_t N = n_traffic, D = 5 + 3 * n_traffic;
     int64_t n_done = 0;
+    /* envs are independent (no cross-env reads anywhere in the reference): with -fopenmp the batch is
+     * spread over the host cores (acas2d_oracle_set_threads), the result is the same bit for bit */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+ : n_done)
+#endif
     for (int64_t e = 0; e < n_envs; ++e) {
         double *o = obs + e * D;
 
@@ -351,4 +356,21 @@ int64_t acas2d_oracle_step(const Acas2dOracleConfig *cfg, const Acas2dOracleStat
         observe_env(cfg, st, e, N, &fresh, o);                                /* environment.py:44-48 */
     }
     return n_done;
+}
+
+/* number of host threads acas2d_oracle_step() uses (1 = the scalar port the bench reports as
+ * cpu_baseline; 0 = all cores).  Returns the number in effect; always 1 without OpenMP. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int acas2d_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n <= 0) n = omp_get_num_procs();
+    omp_set_num_threads(n);
+    return n;
+#else
+    (void)n;
+    return 1;
+#endif
 }

@@ -105,4 +105,7 @@ double acas2d_oracle_goal_distance_reward(double d_goal, double d_goal_max);    
 #ifdef __cplusplus
 }
 #endif
+/* host threads used by acas2d_oracle_step(): 1 = scalar port, 0 = all cores; returns the number in effect */
+int acas2d_oracle_set_threads(int n);
+
 #endif

@@ -95,6 +95,9 @@ def lib():
                         ("plan_deviation_reward", 2), ("goal_distance_reward", 2)):
             f = getattr(_lib, "acas2d_oracle_" + name)
             f.restype, f.argtypes = d, [d] * n
+        _lib.acas2d_oracle_set_threads.restype = C.c_int
+        _lib.acas2d_oracle_set_threads.argtypes = [C.c_int]
+        _lib.acas2d_oracle_set_threads(1)                 # the scalar port unless a caller asks otherwise
         _lib.acas2d_oracle_philox4x32_10.restype = None
         _lib.acas2d_oracle_philox4x32_10.argtypes = [C.c_void_p] * 3
         _lib.acas2d_oracle_reset.restype = None
@@ -107,6 +110,11 @@ def lib():
         _lib.acas2d_oracle_step.argtypes = [C.POINTER(OracleConfig), C.POINTER(OracleState)] + \
             [C.c_void_p] * 8 + [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32]
     return _lib
+
+
+def set_threads(n):
+    """Host threads for OracleEnvs.step(): 1 = scalar port (default), 0 = all cores.  Returns the count."""
+    return int(lib().acas2d_oracle_set_threads(int(n)))
 
 
 def philox4x32_10(ctr, key):
