@@ -208,3 +208,27 @@ def test_sharding_invariance_of_reset_stream(O):
     other = O.OracleEnvs(64, N, seed=8, auto_reset=True)
     other.reset()
     assert not np.array_equal(other.own_psi, full.own_psi)
+
+
+def test_oracle_threads_do_not_change_a_bit(oracle_mod):
+    """The oracle's optional OpenMP spread over envs (bench.py's multi_core CPU number): envs are
+    independent, so any thread count gives the scalar port's results bit for bit."""
+    O = oracle_mod
+    E, N = 5000, 3
+    rng = np.random.default_rng(3)
+    acts = rng.uniform(-1, 1, (40, E))
+    runs = []
+    try:
+        for threads in (1, 0):
+            assert O.set_threads(threads) >= 1
+            env = O.OracleEnvs(E, N, seed=5, auto_reset=True)
+            env.reset()
+            fin = 0
+            for a in acts:
+                fin += env.step(a)[4]
+            runs.append((env.obs.copy(), env.total_reward.copy(), env.episode.copy(), env.trf_x.copy(), fin))
+    finally:
+        O.set_threads(1)
+    assert runs[0][4] == runs[1][4] > 0
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert np.array_equal(a, b)
