@@ -128,8 +128,9 @@ class PPOTrainer:
         self.device = venv.device
         self.policy = (policy or ActorCritic(venv.obs_dim)).to(self.device)
         self.use_graphs = (torch.device(self.device).type == "cuda") if use_graphs is None else bool(use_graphs)
+        # (fused: one multi-tensor kernel for the 13 parameter tensors instead of ~10 foreach launches)
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5,
-                                    capturable=self.use_graphs)
+                                    capturable=self.use_graphs, **({"fused": True} if self.use_graphs else {}))
         self.obs = venv.reset().to(torch.float32).clone()
         # Exact parallel flight makes the reference's d_cpa 0/0 = NaN (kinematics.py:48), and its reward
         # with it when the aircraft is traffic[0]; the engine reproduces that.  In float64 it all but
