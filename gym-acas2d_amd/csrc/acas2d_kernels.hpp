@@ -980,6 +980,89 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
     ACAS2D_STAMP(11, wave_dbg, lane, false);
 }
 
+// Several finished envs of one wave reset SIDE BY SIDE (packed shapes with N + 1 <= 32).  A wave that
+// holds two finished envs used to reset them one after the other -- and with ~190 resets per step over
+// 2 048 waves there is such a wave in almost every launch, so the kernel ended two reset chains after
+// everybody else (limiting the resets to one per wave and step, as an experiment: 6.02 -> 5.48 us).
+// The 64 lanes are cut into SLOTS = 64 / STRIDE slots of STRIDE = pow2 >= N + 1 lanes; slot k takes the
+// k-th finished env, lane `ent` of a slot the entity `ent` (0 the player, n + 1 traffic n): the same
+// per-lane functions as wave_reset_env(), hence the same bits, for up to SLOTS envs in the time of one.
+// Each slot leaves its state in its own 4N+1-value scratch and the first observation in its env's row.
+template <int NS> struct ResetSlots {
+    static constexpr int ENT = NS + 1;
+    static constexpr int STRIDE = ENT <= 2 ? 2 : ENT <= 4 ? 4 : ENT <= 8 ? 8 : ENT <= 16 ? 16 : ENT <= 32 ? 32 : 64;
+    static constexpr int SLOTS = 64 / STRIDE;
+};
+
+// Resets the envs named by the lowest min(SLOTS, popcount(dm)) bits of `dm` (bit = lane of the env's
+// group leader, i.e. el * G); returns the mask of those bits.  Owner lanes find their slot as the rank of
+// their bit in the returned mask.  Whole wave, wave-uniform arguments.
+template <typename T, bool FAST, int NS, int G, typename R>
+__device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& p, const ResetParamsT<R>& rp,
+                                                               const StepIO<T>& io, uint32_t k0, uint32_t k1,
+                                                               uint64_t gid_wave, unsigned long long dm, int lane,
+                                                               uint32_t episode_lane, T* __restrict__ tile,
+                                                               T* __restrict__ scratch) {
+    using RS = ResetSlots<NS>;
+    constexpr int N = NS, D = 5 + 3 * NS, SCR = 4 * NS + 1;
+    const int slot = lane / RS::STRIDE, ent = lane % RS::STRIDE;
+    // slot k <- the k-th set bit of dm
+    unsigned long long taken = 0;
+    int src = 0;                                          // the lane of my slot's env's group leader
+    bool have = false;
+    for (int k = 0; k < RS::SLOTS && dm != 0; ++k) {       // wave-uniform, usually one or two trips
+        const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);
+        dm &= dm - 1;
+        taken |= 1ull << b;
+        if (slot == k) { src = b; have = true; }
+    }
+    const int e = src / G;                                // my slot's env (in the wave)
+    T* row = tile + e * D;
+    T* scr = scratch + slot * SCR;
+    // the finished episodes' last observations: LDS reads now, stores after the Philox block
+    constexpr int TERM_PASSES = (D + RS::STRIDE - 1) / RS::STRIDE;
+    T term_v[TERM_PASSES];
+    if (io.term_obs) {
+#pragma unroll
+        for (int q = 0; q < TERM_PASSES; ++q) {
+            const int i = ent + q * RS::STRIDE;
+            term_v[q] = (have && i < D) ? row[i] : T(0);
+        }
+    }
+    const uint32_t episode = (uint32_t)__shfl((int)episode_lane, src, 64) + 1u;
+    wave_lds_fence();                                     // row reads precede their rewrite below
+    const uint64_t gid = gid_wave + (uint64_t)e;
+    T tx = T(0), ty = T(0), tpsi = T(0), tv = T(0);
+    const bool mine = have && ent <= N;
+    if (mine) {
+        reset_entity<T, R>(rp, k0, k1, (uint32_t)gid, (uint32_t)(gid >> 32), episode, ent, tx, ty, tpsi, tv);
+        if (ent == 0) scr[4 * N] = tpsi;
+        else { const int n = ent - 1; scr[n] = tx; scr[N + n] = ty; scr[2 * N + n] = tpsi; scr[3 * N + n] = tv; }
+    }
+    if (io.term_obs) {
+#pragma unroll
+        for (int q = 0; q < TERM_PASSES; ++q) {
+            const int i = ent + q * RS::STRIDE;
+            if (have && i < D) (io.term_obs + e * D)[i] = term_v[q];
+        }
+    }
+    wave_lds_fence();                                     // the player's heading of every slot is in its scratch
+    const T psi_own = have ? scr[4 * N] : T(0);
+    const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+    const OwnCtx<T> c = own_context<T, FAST>(p, o);
+    // environment.py:44-48: the new episodes' first observations (steps becomes 1)
+    if (mine) {
+        if (ent >= 1) {
+            T d, dca, vc;
+            traffic_step<T, FAST>(p, c, false, tx, ty, tpsi, tv, d, dca, vc);
+            put_traffic_obs<T, FAST>(p, row + 5 + 3 * (ent - 1), d, dca, vc);
+        } else {
+            put_own_obs<T, FAST>(p, row, 1, o.psi, c);
+        }
+    }
+    return taken;
+}
+
 // Flush the wave's LDS tile (`count` values, the contiguous slice dst[0 .. count) of obs[E][D])
 // with lane-linear stores: 16 bytes per lane where the slice is 16-byte aligned, else one value.
 // Chunk c (16 bytes, or one value on the unaligned path) is always written by lane c % 64, so a
@@ -1308,7 +1391,43 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // row: 0.8 us of the 7.7 us launch at 65 536 x 8.)
             bool fresh = false;
             unsigned long long dm = __ballot(oc != 0 && j == 0);
-            while (dm) {
+            constexpr bool SLOTTED = ResetSlots<NS>::SLOTS >= 2;      // N + 1 <= 32: several envs per pass
+            if constexpr (SLOTTED) {
+                while (dm) {
+                    wave_lds_fence();                     // every row of the tile is complete
+                    const unsigned long long taken =
+                        wave_reset_slots<T, FAST, NS, G>(p, rp, io, k0, k1, (uint64_t)(env_offset + e_wave), dm, lane,
+                                                         episode, tile, scratch);
+                    dm &= ~taken;
+                    wave_lds_fence();                     // the fresh rows and the scratches are complete
+                    if ((taken >> (el * G)) & 1ull) {     // my env was reset: its owner group goes on with the new episode
+                        const int k_own = __popcll(taken & ((1ull << (el * G)) - 1ull));
+                        const T* scr = scratch + k_own * (4 * NS + 1);
+                        if (j == 0) {
+                            if (io.ep_return) io.ep_return[el] = total;
+                            if (io.ep_steps) io.ep_steps[el] = steps;
+                        }
+#pragma unroll
+                        for (int k = 0; k < C; ++k) {
+                            const int n = j * C + k;
+                            tr.x.v[k] = scr[n]; tr.y.v[k] = scr[N + n];
+                            tr.psi.v[k] = scr[2 * N + n]; tr.v.v[k] = scr[3 * N + n];
+                        }
+                        o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, scr[4 * N], (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+                        steps = 1;                                            // environment.py:47
+                        total = T(0);
+                        episode += 1u;
+                        fresh = true;
+                        trig.valid = false; trig.dirty = false;   // new headings (stored below)
+                        using V = Vec<T, C>;
+                        const int i0 = el * N + j * C;
+                        *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+                        *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
+                    }
+                    wave_lds_fence();                     // the scratches are free for the next pass
+                }
+            }
+            while (!SLOTTED && dm) {
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);   // wave-uniform
                 dm &= dm - 1;
                 const int el_d = src / G;

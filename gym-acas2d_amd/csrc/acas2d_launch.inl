@@ -63,7 +63,10 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
     const int64_t blocks = (n_envs + envs_per_block - 1) / envs_per_block;
     if (blocks > 0x7fffffffLL) { set_error("n_envs = %lld exceeds the grid limit", (long long)n_envs); return ACAS2D_EINVAL; }
     const int W = 16 / (int)sizeof(T);
-    const int64_t scratch = sh.packed ? 4 * (int64_t)n_traffic + 1 : 0;   // reset hand-off, per wave
+    // reset hand-off, per wave: one 4N+1-value scratch per reset slot (ResetSlots<N> in the kernels)
+    int64_t slots = 1;
+    if (sh.packed && n_traffic + 1 <= 32) { int stride = 2; while (stride < n_traffic + 1) stride *= 2; slots = 64 / stride; }
+    const int64_t scratch = sh.packed ? slots * (4 * (int64_t)n_traffic + 1) : 0;
     const int64_t elems = ((epw * (5 + 3 * (int64_t)n_traffic) + scratch + W - 1) / W) * W;
     const int64_t bytes = elems * kWavesPerBlock * (int64_t)sizeof(T);
     if (bytes > 64 * 1024) {
