@@ -444,7 +444,9 @@ struct Seen {
     int collided;
 };
 
-template <typename T, bool FAST>
+// ZERO_ACTION (a freshly reset episode: a_lat = 0, heading in [0, 360)): the one-step-ahead heading
+// of closing_speed() is the heading itself, bit for bit, so its sin / cos are not computed twice.
+template <typename T, bool FAST, bool ZERO_ACTION = false>
 __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T>& o) {
     OwnCtx<T> c;
     c.x = o.x; c.y = o.y; c.v = o.v;
@@ -455,9 +457,11 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
 #endif
     if constexpr (FAST) {
         f_sincos_rev(o.psi * Const<T>::inv360, &c.so, &c.co);
-        T psi1 = wrap360_window(o.psi + (o.a_lat * f_rcp(o.v)) * p.dt);
-        T s1, c1;
-        f_sincos_rev(psi1 * Const<T>::inv360, &s1, &c1);
+        T s1 = c.so, c1 = c.co;
+        if constexpr (!ZERO_ACTION) {
+            T psi1 = wrap360_window(o.psi + (o.a_lat * f_rcp(o.v)) * p.dt);
+            f_sincos_rev(psi1 * Const<T>::inv360, &s1, &c1);
+        }
         const T vdt = o.v * p.dt;
         c.v1x = rounded(vdt * c1); c.v1y = rounded(vdt * s1);
         c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
@@ -467,10 +471,12 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
         c.d_dev = gdy;            // d_goal * sin(atan2(gdy, gdx)) == gdy          (game.py:175-180)
     } else {
         m_sincos(deg2rad_ref(o.psi), &c.so, &c.co);
-        // psi_dot = a_lat / v: no /dt here, unlike aircraft.py:20
-        T psi1 = py_mod360(o.psi + ((o.a_lat / o.v) * p.dt));
-        T s1, c1;
-        m_sincos(deg2rad_ref(psi1), &s1, &c1);
+        T s1 = c.so, c1 = c.co;
+        if constexpr (!ZERO_ACTION) {
+            // psi_dot = a_lat / v: no /dt here, unlike aircraft.py:20
+            T psi1 = py_mod360(o.psi + ((o.a_lat / o.v) * p.dt));
+            m_sincos(deg2rad_ref(psi1), &s1, &c1);
+        }
         c.v1x = (o.v * c1) * p.dt; c.v1y = (o.v * s1) * p.dt;
         c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
         c.d_goal = distance(o.x, o.y, o.gx, o.gy);                                // game.py:168-169
@@ -946,7 +952,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
     if constexpr (kOneTermPass) { if (io.term_obs && lane < D) (io.term_obs + e * D)[lane] = term_v; }
     psi_own = lane_value(psi_own, 0);
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-    const OwnCtx<T> c = own_context<T, FAST>(p, o);
+    const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
 
     ACAS2D_STAMP(10, wave_dbg, lane, false);
     // environment.py:44-48: the new episode's first observation (steps becomes 1)
@@ -1049,7 +1055,7 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
     wave_lds_fence();                                     // the player's heading of every slot is in its scratch
     const T psi_own = have ? scr[4 * N] : T(0);
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-    const OwnCtx<T> c = own_context<T, FAST>(p, o);
+    const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
     // environment.py:44-48: the new episodes' first observations (steps becomes 1)
     if (mine) {
         if (ent >= 1) {
