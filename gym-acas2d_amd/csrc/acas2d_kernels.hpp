@@ -1052,8 +1052,19 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
             if (have && i < D) (io.term_obs + e * D)[i] = term_v[q];
         }
     }
-    wave_lds_fence();                                     // the player's heading of every slot is in its scratch
-    const T psi_own = have ? scr[4 * N] : T(0);
+    // every lane of a slot needs its player's heading (lane 0 of the slot): a 16-lane slot is one DPP
+    // row (row_newbcast:0), smaller slots sit inside a quad; otherwise through the slot's scratch
+    T psi_own;
+    if constexpr (sizeof(T) == 4 && RS::STRIDE == 16)
+        psi_own = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int((float)tpsi), 0x150, 0xf, 0xf, false));
+    else if constexpr (sizeof(T) == 4 && RS::STRIDE == 4)
+        psi_own = __int_as_float(quad_perm<0x00>(__float_as_int((float)tpsi)));
+    else if constexpr (sizeof(T) == 4 && RS::STRIDE == 2)
+        psi_own = __int_as_float(quad_perm<0xA0>(__float_as_int((float)tpsi)));
+    else {
+        wave_lds_fence();                                 // the player's heading of every slot is in its scratch
+        psi_own = have ? scr[4 * N] : T(0);
+    }
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
     const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
     // environment.py:44-48: the new episodes' first observations (steps becomes 1)
