@@ -1015,12 +1015,14 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
     // slot k <- the k-th set bit of dm
     unsigned long long taken = 0;
     int src = 0;                                          // the lane of my slot's env's group leader
+    uint32_t episode_prev = 0;
     bool have = false;
     for (int k = 0; k < RS::SLOTS && dm != 0; ++k) {       // wave-uniform, usually one or two trips
         const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);
         dm &= dm - 1;
         taken |= 1ull << b;
-        if (slot == k) { src = b; have = true; }
+        const uint32_t ep_b = (uint32_t)lane_value((int)episode_lane, b);    // v_readlane: b is wave-uniform
+        if (slot == k) { src = b; have = true; episode_prev = ep_b; }
     }
     const int e = src / G;                                // my slot's env (in the wave)
     T* row = tile + e * D;
@@ -1035,7 +1037,7 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
             term_v[q] = (have && i < D) ? row[i] : T(0);
         }
     }
-    const uint32_t episode = (uint32_t)__shfl((int)episode_lane, src, 64) + 1u;
+    const uint32_t episode = episode_prev + 1u;
     wave_lds_fence();                                     // row reads precede their rewrite below
     const uint64_t gid = gid_wave + (uint64_t)e;
     T tx = T(0), ty = T(0), tpsi = T(0), tv = T(0);
