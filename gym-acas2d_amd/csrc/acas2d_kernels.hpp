@@ -1304,7 +1304,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
 
     // Launch constants into VGPRs only now, AFTER the loads are in flight: pinned() is ~25 v_movs
     // behind a kernarg s_load round trip, which used to sit in front of the first global load.
-    const Params<T> p = pinned(p_arg);
+    // (not for the policy rollout: its MLP needs the 25 registers more than it minds re-fetching
+    // launch constants, and has to stay under 256 VGPRs to keep two waves per SIMD)
+    const Params<T> p = POLICY ? p_arg : pinned(p_arg);
     if constexpr (AUTO_RESET && !ROLLOUT) {
         // ... and what the reset of a finished env reads, so that its wave does not start the reset
         // with a scalar-load round trip (the kernel ends with that wave)
@@ -1336,7 +1338,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             float x[DP];
 #pragma unroll
             for (int i = 0; i < DP; ++i) x[i] = (float)row[i];
-            action = (T)policy_action<DP>(pw, x);
+            // The weights must be RE-READ every step (scalar cache hits): they are loop-invariant, and
+            // hoisted out of the step loop hipcc tries to keep all 4 700 of them in SGPRs, spills them
+            // to VGPR lanes and reads them back one v_readlane at a time (7x slower).  Laundering the
+            // pointers through an empty asm makes the loads depend on the iteration.
+            PolicyW pw_t = pw;
+            asm volatile("" : "+s"(pw_t.w1t), "+s"(pw_t.b1), "+s"(pw_t.w2t), "+s"(pw_t.b2), "+s"(pw_t.w3), "+s"(pw_t.b3));
+            action = (T)policy_action<DP>(pw_t, x);
             if (active) (static_cast<T*>(pw.actions_out) + e_wave + te)[el] = action;
         } else {
             if (ROLLOUT && active && t + 1 < T_steps) action_next = io.actions[n_envs + el];
