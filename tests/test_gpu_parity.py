@@ -609,6 +609,18 @@ def test_fused_policy_rollout_reproduces_the_reference_policy_evaluation(g):
     oc, steps, ret = _first_episode(out, 100)
     assert (oc == 1).all()
     H.assert_matches_reference_policy_eval(ret, steps, 2.0 * (steps - 1), tol=1e-4)
+    # a loose speed floor: the in-kernel MLP once regressed 7x (its weight loads were hoisted out of the
+    # step loop and spilled) without a single wrong bit; 65 536 envs x 100 steps take ~1.5 ms
+    big = g.ACAS2DVecEnv(65536, 1, device="cuda:0", dtype=torch.float32, seed=1)
+    big.reset()
+    o = big.rollout_policy(pol, 100)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    big.rollout_policy(pol, 100, out=o)
+    t1.record()
+    torch.cuda.synchronize()
+    assert t0.elapsed_time(t1) < 6.0, t0.elapsed_time(t1)
     # the convenience wrapper, and the step-by-step evaluation it replaces
     fused = g.evaluate_policy_fused(pol, own, trf, goal)
     assert fused["unfinished"] == 0 and np.array_equal(fused["outcome"], oc) and np.array_equal(fused["steps"], steps)
