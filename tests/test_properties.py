@@ -1,13 +1,16 @@
 """Property tests (hypothesis) of one step on arbitrary states, CPU oracle: the invariants the
 reference's state machine guarantees (game.py:194-314), independent of any golden vector."""
 import numpy as np
-from hypothesis import given, settings, strategies as st
+from hypothesis import example, given, settings, strategies as st
 
 coord = st.floats(-300, 1900, allow_nan=False, width=64)
 heading = st.floats(0, 360, allow_nan=False, width=64)
 
 
-@settings(max_examples=150, deadline=None)
+# derandomize + database=None: the suite must not depend on a local .hypothesis/ example database;
+# the @example is the over-time case round 1's bound missed (steps + 1 = 1002 -> tdf = -0.002).
+@settings(max_examples=150, deadline=None, derandomize=True, database=None)
+@example(own=(0.0, 176.0, 0.0), trf=[(0.0, 0.0, 0.0)], steps=1001, action=0.0)
 @given(own=st.tuples(coord, coord, heading), trf=st.lists(st.tuples(coord, coord, heading), min_size=1, max_size=9),
        steps=st.integers(0, 1002), action=st.floats(-1, 1, allow_nan=False, width=64))
 def test_step_invariants(oracle_mod, own, trf, steps, action):
@@ -37,7 +40,10 @@ def test_step_invariants(oracle_mod, own, trf, steps, action):
     assert np.all(obs[0, 5::3] >= 0) and abs(obs[0, 3] * c.d_goal_max - d_goal) < 1e-9
     assert abs(obs[0, 1] * 360 - env.own_psi[0]) < 1e-12
     np.testing.assert_allclose(obs[0, 5::3] * c.d_sep_max, d, atol=1e-9)
-    # reward: shaped part in [-0.001, 1] (tdf can be -0.001 on the timeout step) plus terminal bonuses
+    # reward: r_step in [0, 1] times tdf = 1 - steps/MAX_STEPS with the incremented counter (game.py:262-263;
+    # negative once the counter is past MAX_STEPS: -0.001 on the timeout step itself, lower for a state
+    # injected beyond it), plus the terminal bonuses
     if np.isfinite(r[0]) and not near:
         shaped = r[0] - (-1000 if (d < 96).any() else 0) - (1000 if d_goal < 144 else 0)
-        assert -0.0011 <= shaped <= 1.0 + 1e-12
+        tdf = 1.0 - (steps + 1) / c.max_steps
+        assert min(0.0, tdf) - 1e-9 <= shaped <= max(0.0, tdf) + 1e-9
