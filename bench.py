@@ -2,8 +2,10 @@
 """bench.py -- env-steps/s of the batched ACAS2D step engine on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no torchrun environment, this process only starts the ranks (a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` of this
+same file) and exits with their return code; launched under torchrun it is one of the ranks.
 
 A "step" is one pass of the hot path over one batch: ONE VecEnv step() = one launch of the step
 kernel over all envs of the rank (action -> integrate -> observe -> evaluate -> is_done ->
@@ -14,14 +16,26 @@ HBM-resident buffers every step.  Workload at every N: BASELINE.json configs[2] 
 region.  Multi-GPU = independent env shards (global env index = rank * envs + e), no collective
 on the step path (weak scaling); the only communication is the timing barrier / MAX.
 
+Timing.  The K steps are captured once into hipGraphs (chunks that divide K) and the graphs are
+replayed: after the W warm-up steps the captured graphs are replayed for >= 0.3 s (clocks up, the
+graph uploaded -- a first replay is several times slower than a steady one), then the timed region
+runs the K steps R times back to back between barrier + synchronize on both sides; R ("repeats")
+is 1 for K >= 2000 and ceil(2000 / K) below that, so that one graph-launch latency (~15-40 us) is
+not smeared over a handful of 5 us steps.  `ms_per_step`, `value` and `roofline` are means over the
+K * R timed steps.
+
 One JSON line on rank 0 with `roofline` (HBM bound; algorithmic bytes B(N,s) = s(16+9N)+9 per
 env-step / average launch duration measured with HIP events on the launch stream) and
-`cpu_baseline` (the CPU oracle = a scalar float64 port of the reference step, timed on this
-box's host cores on a bounded sample).
+`cpu_baseline` (the CPU oracle = a scalar float64 C port of the reference step, timed on this
+box's host cores on a bounded sample: the like-for-like single-env loop of BASELINE.json
+configs[0] and the batch of the headline workload).
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,13 +43,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable copy)
+METRIC = "env-steps/sec at 65536 envs x N_TRAFFIC=8; achieved HBM GB/s vs peak"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -44,28 +56,84 @@ def parse():
     ap.add_argument("--traffic", type=int, default=8)
     ap.add_argument("--dtype", choices=("f32", "f64"), default="f32")
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
-                    help="replay the step launches from a captured hipGraph (default) or launch eagerly")
-    ap.add_argument("--chunk", type=int, default=100, help="steps per captured graph / action rows")
+                    help="replay the step launches from captured hipGraphs (default) or launch eagerly")
+    ap.add_argument("--chunk", type=int, default=200, help="largest number of steps per captured graph")
+    ap.add_argument("--repeats", type=int, default=0, help="timed repetitions of the K steps (0 = auto: ceil(2000 / K))")
+    ap.add_argument("--spin-seconds", type=float, default=0.3, help="graph replays before the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="rehearsal only: force this GPU index on every rank")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="no engine, no GPU: a stand-in step on the CPU, to exercise the launcher / rendezvous / "
+                         "barrier / MAX-over-ranks / JSON path (tests); the line says so and carries no roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary fused-rollout measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other single-GPU BASELINE configs")
     ap.add_argument("--rollout-steps", type=int, default=200)
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic: latch outcomes instead of resetting")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-collisions", action="store_true",
                     help="diagnostic (SURVEY.md 8d, C4): collision distance 0, so episodes end at the goal / by "
                          "timeout only and resets are rare -- isolates the step itself at large N_TRAFFIC")
-    return ap.parse_args()
+    ap.add_argument("--no-terminations", action="store_true",
+                    help="diagnostic: no collisions, no goal, no timeout -- nothing ever finishes (the reset-free floor)")
+    return ap.parse_args(argv)
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """--gpus N > 1 from a plain `python bench.py`: start the N ranks as a CHILD process (never exec: this
+    process may not be replaced once anything touched the GPU, and nothing has yet -- only `import`s ran)
+    and hand its return code back."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---- CPU baselines (the oracle as the thing timed beside the GPU, never as the product) --------------
 def cpu_baseline(envs, traffic, seconds):
-    """The oracle (scalar C float64 port of the reference step, 1 thread) on a bounded sample of
-    the same workload: the same env count and traffic, as many steps as fit in ~`seconds`."""
+    """The oracle (scalar C float64 port of the reference step) on bounded samples.
+    `value`: the headline workload's batch (same env count and traffic), 1 thread, as many steps as fit
+    in ~`seconds`.  `single_env`: BASELINE.json configs[0] / BASELINE.md section 3's like-for-like line --
+    ONE env, N_TRAFFIC = 3, random actions, auto-reset, one core, stepped in sequence."""
+    import numpy as np
     from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    # -- like-for-like: 1 env x 3 traffic, sequential step() calls on one core
+    one = O.OracleEnvs(1, 3, seed=13, auto_reset=True)
+    one.reset()
+    one.single_env_loop(rng.uniform(-1, 1, 1000))
+    n1, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 1.5:
+        one.single_env_loop(rng.uniform(-1, 1, 100000))
+        n1 += 100000
+    dt1 = time.perf_counter() - t0
+    acts1 = rng.uniform(-1, 1, 20000)
+    t0 = time.perf_counter()
+    for a in acts1:
+        one.step([a])
+    dt1py = time.perf_counter() - t0
+    single = {"value": n1 / dt1, "unit": "env-steps/s", "cores": 1, "kind": "port",
+              "sample": "1 env x 3 traffic, %d sequential step() calls in C (oracle/acas2d_oracle.c "
+                        "acas2d_oracle_single_env_loop), auto-reset, %.1f s" % (n1, dt1),
+              "through_python_binding": {"value": len(acts1) / dt1py, "unit": "env-steps/s",
+                                         "sample": "the same env, %d step() calls one ctypes call each" % len(acts1)},
+              "reference_python_step": {"value": 5950.0, "unit": "env-steps/s",
+                                        "note": "the real reference step(), clock throttle stubbed, timed in the build "
+                                                "container only (it cannot travel): BASELINE.md section 2, Xeon 2.1 GHz, "
+                                                "1 thread; as shipped it sleeps to <= 100 steps/s (environment.py:31)"}}
+    # -- the headline batch on one thread
     env = O.OracleEnvs(envs, traffic, seed=13, auto_reset=True)
     env.reset()
-    rng = np.random.default_rng(0)
     acts = rng.uniform(-1, 1, (8, envs))
     env.step(acts[0])
     t0 = time.perf_counter()
@@ -79,7 +147,8 @@ def cpu_baseline(envs, traffic, seconds):
     out = {"value": envs * n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": "%d envs x %d traffic x %d steps, float64 scalar C port of the reference step "
                      "(oracle/acas2d_oracle.c), 1 thread of %d host cpus, %.1f s" %
-                     (envs, traffic, n, os.cpu_count() or 0, dt)}
+                     (envs, traffic, n, os.cpu_count() or 0, dt),
+           "single_env": single}
     # the same port spread over host cores (OpenMP over envs), a few seconds more
     # (16 = the CPU share of a one-GPU box; asking for all 256 logical CPUs there is slower than one)
     cores = O.set_threads(min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0))))
@@ -87,7 +156,7 @@ def cpu_baseline(envs, traffic, seconds):
         if cores > 1:
             env.step(acts[0])
             t0, m = time.perf_counter(), 0
-            while time.perf_counter() - t0 < min(4.0, seconds) and m < 2000:
+            while time.perf_counter() - t0 < min(3.0, seconds) and m < 2000:
                 env.step(acts[m % 8])
                 m += 1
             dt = time.perf_counter() - t0
@@ -110,80 +179,181 @@ def load_traffic(envs, traffic, dtype):
     return None
 
 
+def pick_chunk(k, cap):
+    """Steps per captured graph: the largest divisor of K that is <= cap, so that the K timed steps are
+    whole replays; a K with no useful divisor keeps `cap` and runs the remainder eagerly."""
+    cap = max(1, min(cap, k))
+    best = max(d for d in range(1, cap + 1) if k % d == 0)
+    return best if best * 10 >= cap else cap
+
+
+class StepRunner:
+    """`chunk` consecutive step() launches (row t of a resident [chunk, E] action buffer each) captured
+    into one hipGraph; run(n) = n // chunk replays + the remainder eagerly."""
+
+    def __init__(self, env, actions, use_graph):
+        import torch
+        self.env, self.rows, self.chunk = env, [actions[t] for t in range(actions.shape[0])], actions.shape[0]
+        self.graph = None
+        if use_graph:
+            self.eager(3)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.eager(self.chunk)
+
+    def eager(self, n):
+        for t in range(n):
+            self.env.step_from(self.rows[t % self.chunk])
+
+    def run(self, n):
+        if self.graph is None:
+            self.eager(n)
+            return
+        full, rest = divmod(n, self.chunk)
+        for _ in range(full):
+            self.graph.replay()
+        self.eager(rest)
+
+    def spin(self, seconds):
+        """Replay for `seconds` of wall time (at least once): the graph is uploaded and the clocks are up
+        before anything is timed."""
+        import torch
+        n, t0 = 0, time.perf_counter()
+        while True:
+            self.run(self.chunk)
+            n += 1
+            if n % 8 == 0 or self.graph is None:
+                torch.cuda.synchronize()
+            if time.perf_counter() - t0 >= seconds:
+                break
+        torch.cuda.synchronize()
+        return n
+
+
+def make_env(g, E, N, dtype, dev, rank, args):
+    env = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13, env_offset=rank * E,
+                         auto_reset=not args.no_auto_reset)
+    if args.no_collisions or args.no_terminations:
+        env._ccfg.collision_dist = 0.0
+    if args.no_terminations:
+        env._ccfg.goal_radius = 0.0
+        env._ccfg.max_steps = 2 ** 30
+    env.reset()
+    return env
+
+
+def time_config(g, E, N, dtype_name, dev, args, steps=1000, chunk=100):
+    """One secondary single-GPU configuration: per-launch time by HIP events over `steps` graph-replayed
+    steps after a short spin.  Returns the numbers of the roofline line for that workload."""
+    import torch
+    dtype = torch.float32 if dtype_name == "f32" else torch.float64
+    env = make_env(g, E, N, dtype, dev, 0, args)
+    gen = torch.Generator(device=dev).manual_seed(1000)
+    actions = torch.rand(chunk, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
+    runner = StepRunner(env, actions, True)
+    runner.spin(0.1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    runner.run(steps)
+    ev1.record()
+    torch.cuda.synchronize()
+    us = ev0.elapsed_time(ev1) * 1e3 / steps
+    s = 4 if dtype_name == "f32" else 8
+    b = E * g.ACAS2DConfig.algorithmic_bytes_per_env_step(N, s)
+    geo = g.native.launch_geometry(E, N, s)
+    out = {"workload": "%d envs x N_TRAFFIC=%d, %s" % (E, N, dtype_name), "launch_us": us,
+           "env_steps_per_s": E / (us * 1e-6), "algorithmic_bytes_per_launch": b,
+           "achieved_GBps": b / (us * 1e-6) / 1e9, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"], "steps": steps}
+    del runner, env, actions
+    return out
+
+
+class RehearsalEnv:
+    """--rehearsal: NOT the engine.  A stand-in with the one method the timing loop calls, on the CPU, so
+    that the launcher / rendezvous / barrier / MAX / JSON path can be exercised where no GPU exists."""
+
+    def __init__(self, E):
+        import torch
+        self.acc = torch.zeros(E)
+        self.episode = torch.zeros(E, dtype=torch.int32)
+
+    def step_from(self, row):
+        self.acc.add_(row)
+
+
 def main():
     args = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world_env == 0 and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
+
+    import torch
     import gym_acas2d_amd as g
     if os.environ.get("ACAS2D_BENCH_LIB"):        # diagnostic builds (tools/): ablation / stamps
         g.native.LIB_PATH = os.path.join(ROOT, "gym-acas2d_amd", "csrc", os.environ["ACAS2D_BENCH_LIB"])
     rank, local_rank, world = g.sharding.dist_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
-    dev_index = local_rank if args.device is None else args.device
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    g.sharding.init_process_group(args.backend)
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    args.gpus = world
     E, N, K, W = args.envs, args.traffic, args.steps, args.warmup
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
 
-    env = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13, env_offset=rank * E,
-                         auto_reset=not args.no_auto_reset)
-    if args.no_collisions:
-        env._ccfg.collision_dist = 0.0
-    env.reset()
-    chunk = max(1, min(args.chunk, K))
+    if args.rehearsal:
+        dev = torch.device("cpu")
+        g.sharding.init_process_group("gloo")
+        env = RehearsalEnv(E)
+        sync = lambda: None  # noqa: E731
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+        dev_index = local_rank if args.device is None else args.device
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        g.sharding.init_process_group(args.backend)
+        env = make_env(g, E, N, dtype, dev, rank, args)
+        sync = torch.cuda.synchronize
+
+    chunk = pick_chunk(K, args.chunk)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     actions = torch.rand(chunk, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
-    rows = [actions[t] for t in range(chunk)]
-
-    def run_eager(n, start=0):
-        for t in range(n):
-            env.step_from(rows[(start + t) % chunk])
-
-    graph = None
-    if args.launch == "graph":
-        run_eager(3)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            run_eager(chunk)
-
-    def run(n):
-        if graph is None:
-            run_eager(n)
-            return
-        full, rest = divmod(n, chunk)
-        for _ in range(full):
-            graph.replay()
-        run_eager(rest)
+    use_graph = args.launch == "graph" and not args.rehearsal
+    runner = StepRunner(env, actions, use_graph)
+    repeats = args.repeats if args.repeats > 0 else (1 if K >= 2000 else min(400, math.ceil(2000 / K)))
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    run(W)
-    torch.cuda.synchronize()
+    # ---- warm-up: the W steps asked for, then the captured graphs replayed for spin-seconds ----
+    runner.run(W)
+    sync()
+    spin_replays = runner.spin(args.spin_seconds) if not args.rehearsal else 0
+    # ---- timed region: the K steps, R times, between barrier + synchronize on both sides ----
+    sync()
     barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    if not args.rehearsal:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()                       # same stream as the kernel launches (torch's current stream)
-    run(K)
-    ev1.record()
-    torch.cuda.synchronize()
+    if not args.rehearsal:
+        ev0.record()                   # same stream as the kernel launches (torch's current stream)
+    for _ in range(repeats):
+        runner.run(K)
+    if not args.rehearsal:
+        ev1.record()
+    sync()
     barrier()
-    torch.cuda.synchronize()
+    sync()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    wall = g.sharding.max_over_ranks(wall, device=dev)
-    dev_ms = g.sharding.max_over_ranks(dev_ms, device=dev)
-    episodes = g.sharding.sum_over_ranks(float(env.episode.to(torch.int64).sum().item()), device=dev)
+    dev_ms = ev0.elapsed_time(ev1) if not args.rehearsal else wall * 1e3
+    red_dev = dev if not args.rehearsal and args.backend == "nccl" else "cpu"
+    wall = g.sharding.max_over_ranks(wall, device=red_dev)
+    dev_ms = g.sharding.max_over_ranks(dev_ms, device=red_dev)
+    episodes = g.sharding.sum_over_ranks(float(env.episode.to(torch.int64).sum().item()), device=red_dev)
+    timed_steps = K * repeats
 
     # ---- secondary: the same workload through acas2d_rollout_* (T steps fused per launch) ----
     fused = None
-    if not args.no_rollout and not args.no_auto_reset:
+    if not args.no_rollout and not args.no_auto_reset and not args.rehearsal:
         try:
             T = args.rollout_steps
             act = torch.rand(T, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
@@ -197,7 +367,7 @@ def main():
                 out = env.rollout(act, out=out)
             r1.record()
             torch.cuda.synchronize()
-            ms = g.sharding.max_over_ranks(r0.elapsed_time(r1), device=dev)
+            ms = g.sharding.max_over_ranks(r0.elapsed_time(r1), device=red_dev)
             sz = 4 if args.dtype == "f32" else 8
             per_step = sz * (7 + 3 * N) + 2                                   # action, obs, reward, done, outcome
             state = sz * (6 + 4 * N) + 12 + sz + sz * (3 + 2 * N) + 4 + sz    # state read + written once per launch
@@ -214,39 +384,61 @@ def main():
     if rank == 0:
         s = 4 if args.dtype == "f32" else 8
         bytes_per_launch = E * g.ACAS2DConfig.algorithmic_bytes_per_env_step(N, s)
-        launch_us = dev_ms * 1e3 / K
+        launch_us = dev_ms * 1e3 / timed_steps
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-        geo = g.native.launch_geometry(E, N, s)
+        diag = ("" if not args.no_collisions else ", collisions disabled (diagnostic)") + \
+               ("" if not args.no_terminations else ", nothing terminates (diagnostic)")
         out = {
-            "metric": "env-steps/sec at 65536 envs x N_TRAFFIC=8; achieved HBM GB/s vs peak",
-            "value": E * world * K / wall,
+            "metric": METRIC,
+            "value": E * world * timed_steps / wall,
             "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall * 1e3 / K,
+            "n_gpus": world, "steps": K, "warmup": W, "repeats": repeats,
+            "ms_per_step": wall * 1e3 / timed_steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "%d envs x N_TRAFFIC=%d per GPU, %s, one step-kernel launch per step(), "
-                                   "auto-reset %s, random actions U(-1,1)%s"
-                                   % (E, N, args.dtype, "off" if args.no_auto_reset else "on",
-                                      ", collisions disabled (diagnostic)" if args.no_collisions else ""),
-                       "envs_per_gpu": E, "n_traffic": N, "launch": args.launch,
-                       "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"],
-                       "grid_blocks": geo["grid_blocks"],
-                       "parallelism": "env-index shards x%d, no collective on the step path" % world,
-                       "episodes_finished": int(episodes)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(E, N, args.dtype),
-                         "kernel": "acas2d::step_kernel<%s, C=%d, G=%d>" % ("float" if s == 4 else "double",
-                                                                            geo["traffic_per_lane"], geo["lanes_per_env"]),
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "launch_us": launch_us},
         }
+        if args.rehearsal:
+            out["rehearsal"] = True
+            out["value"] = None                    # nothing of the engine was measured
+            out["data"] = "rehearsal: NO engine ran (stand-in CPU step); launcher / barrier / MAX-over-ranks path only"
+            out["config"] = {"workload": "rehearsal, %d stand-in values per rank" % E, "envs_per_gpu": E,
+                             "parallelism": "env-index shards x%d, no collective on the step path" % world,
+                             "backend": "gloo", "chunk": chunk}
+            out["roofline"] = None
+        else:
+            geo = g.native.launch_geometry(E, N, s)
+            out["config"] = {"workload": "%d envs x N_TRAFFIC=%d per GPU, %s, one step-kernel launch per step(), "
+                                         "auto-reset %s, random actions U(-1,1)%s"
+                                         % (E, N, args.dtype, "off" if args.no_auto_reset else "on", diag),
+                             "envs_per_gpu": E, "n_traffic": N, "launch": args.launch, "steps_per_graph": chunk,
+                             "warmup_graph_replays": spin_replays,
+                             "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"],
+                             "grid_blocks": geo["grid_blocks"],
+                             "parallelism": "env-index shards x%d, no collective on the step path" % world,
+                             "episodes_finished": int(episodes)}
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(E, N, args.dtype),
+                               "kernel": "acas2d::step_kernel<%s, C=%d, G=%d>" % ("float" if s == 4 else "double",
+                                                                                  geo["traffic_per_lane"], geo["lanes_per_env"]),
+                               "algorithmic_bytes_per_launch": bytes_per_launch,
+                               "launch_us": launch_us}
         if fused is not None:
             out["fused_rollout"] = fused
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.rehearsal and not args.no_extra:
+            # the other single-GPU configurations of BASELINE.json (parity-test cases; reported, not `value`)
+            extra = []
+            for (e2, n2, d2) in ((4096, 3, "f32"), (65536, 64, "f32"), (65536, 8, "f64"), (131072, 8, "f32")):
+                if (e2, n2, d2) == (E, N, args.dtype):
+                    continue
+                try:
+                    extra.append(time_config(g, e2, n2, d2, dev, args))
+                except Exception as e:  # noqa: BLE001
+                    extra.append({"workload": "%d x %d %s" % (e2, n2, d2), "error": str(e)})
+            out["other_configs"] = extra
+        if world == 1 and not args.no_cpu_baseline and not args.rehearsal:
             out["cpu_baseline"] = cpu_baseline(E, N, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

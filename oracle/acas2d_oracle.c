@@ -358,6 +358,24 @@ int64_t acas2d_oracle_step(const Acas2dOracleConfig *cfg, const Acas2dOracleStat
     return n_done;
 }
 
+/* The like-for-like CPU line of BASELINE.md section 3: ONE env stepped n_steps times in sequence,
+ * one acas2d_oracle_step(n_envs = 1) per iteration with action actions[t] and auto-reset on done --
+ * the loop of baseline_main.py:39-61 / the reference's `for t in range(MAX_STEPS): env.step(a)`
+ * without the interpreter around it.  `st`, obs .. ep_steps are the one-env buffers of
+ * acas2d_oracle_step().  Returns the number of episodes that finished. */
+int64_t acas2d_oracle_single_env_loop(const Acas2dOracleConfig *cfg, const Acas2dOracleState *st,
+                                      const double *actions, int64_t n_steps, double *obs, double *reward,
+                                      uint8_t *done, uint8_t *outcome, double *term_obs,
+                                      double *ep_return, int32_t *ep_steps, uint64_t seed,
+                                      int64_t env_offset, int32_t n_traffic)
+{
+    int64_t finished = 0;
+    for (int64_t t = 0; t < n_steps; ++t)
+        finished += acas2d_oracle_step(cfg, st, actions + t, obs, reward, done, outcome, term_obs, ep_return,
+                                       ep_steps, 1, seed, env_offset, 1, n_traffic);
+    return finished;
+}
+
 /* number of host threads acas2d_oracle_step() uses (1 = the scalar port the bench reports as
  * cpu_baseline; 0 = all cores).  Returns the number in effect; always 1 without OpenMP. */
 #ifdef _OPENMP

@@ -93,6 +93,14 @@ int64_t acas2d_oracle_step(const Acas2dOracleConfig *cfg, const Acas2dOracleStat
                            int32_t *ep_steps, int32_t auto_reset, uint64_t seed,
                            int64_t env_offset, int64_t n_envs, int32_t n_traffic);
 
+/* One env, n_steps sequential acas2d_oracle_step(n_envs = 1, auto_reset = 1) calls with actions[t]:
+ * the reference's single-env `env.step(a)` loop (baseline_main.py:39-61) without the interpreter. */
+int64_t acas2d_oracle_single_env_loop(const Acas2dOracleConfig *cfg, const Acas2dOracleState *st,
+                                      const double *actions, int64_t n_steps, double *obs, double *reward,
+                                      uint8_t *done, uint8_t *outcome, double *term_obs,
+                                      double *ep_return, int32_t *ep_steps, uint64_t seed,
+                                      int64_t env_offset, int32_t n_traffic);
+
 /* L1 functions exported one by one for known-answer tests. */
 double acas2d_oracle_distance(double x1, double y1, double x2, double y2);        /* kinematics.py:7-13  */
 double acas2d_oracle_relative_angle(double x1, double y1, double x2, double y2);  /* kinematics.py:16-22 */

@@ -109,6 +109,9 @@ def lib():
         _lib.acas2d_oracle_step.restype = C.c_int64
         _lib.acas2d_oracle_step.argtypes = [C.POINTER(OracleConfig), C.POINTER(OracleState)] + \
             [C.c_void_p] * 8 + [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32]
+        _lib.acas2d_oracle_single_env_loop.restype = C.c_int64
+        _lib.acas2d_oracle_single_env_loop.argtypes = [C.POINTER(OracleConfig), C.POINTER(OracleState), C.c_void_p,
+                                                       C.c_int64] + [C.c_void_p] * 7 + [C.c_uint64, C.c_int64, C.c_int32]
     return _lib
 
 
@@ -180,6 +183,16 @@ class OracleEnvs:
         self.episode[:] = 0
         self.reset_philox()
         return self.observe()
+
+    def single_env_loop(self, actions):
+        """E == 1 only: len(actions) sequential step() calls inside C (auto-reset on done); the state and
+        the output buffers end as after the last step.  Returns the number of finished episodes."""
+        assert self.E == 1 and self.auto_reset
+        a = np.ascontiguousarray(np.asarray(actions, np.float64).reshape(-1))
+        return int(lib().acas2d_oracle_single_env_loop(
+            C.byref(self.cfg), C.byref(self._st), a.ctypes.data, a.size, self.obs.ctypes.data,
+            self.reward.ctypes.data, self.done.ctypes.data, self.outcome.ctypes.data, self.term_obs.ctypes.data,
+            self.ep_return.ctypes.data, self.ep_steps.ctypes.data, self.seed, self.env_offset, self.N))
 
     def step(self, actions):
         a = np.ascontiguousarray(np.asarray(actions, np.float64).reshape(self.E))
