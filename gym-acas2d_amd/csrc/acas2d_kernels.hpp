@@ -44,20 +44,7 @@ namespace acas2d {
 constexpr int kBlock = ACAS2D_BLOCK;      // threads per workgroup (tuning knob; 256 measured best)
 constexpr int kWavesPerBlock = kBlock / 64;
 
-// In-kernel stamps: DIAGNOSTIC build only (tools/diag_stamps.py builds libacas2d_hip_diag.so with
-// -DACAS2D_STAMPS).  In the product build ACAS2D_STAMP() is empty and no stamp executes.
-#ifdef ACAS2D_STAMPS
-static __device__ unsigned long long* g_stamps = nullptr;   // [n_waves][16], set by acas2d_debug_set_stamps_*
-#define ACAS2D_STAMP(k, wave_id, lane_id, drain)                                              \
-    do {                                                                                      \
-        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
-        if ((lane_id) == 0 && g_stamps)                                                       \
-            g_stamps[(wave_id) * 16 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() \
-                                                                   : __builtin_amdgcn_s_memtime();    \
-    } while (0)
-#else
-#define ACAS2D_STAMP(k, wave_id, lane_id, drain) do { } while (0)
-#endif
+#include "acas2d_diag.hpp"   // ACAS2D_STAMP(): empty in the product build
 
 // ---- launch-constant parameters, already rounded to T on the host -----------------------------
 template <typename T>
@@ -369,8 +356,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 // XCD-aware block remap: blocks are dealt round-robin over the 8 XCDs, so give each XCD one
 // contiguous eighth of the env range (its L2 then sees whole cache lines and the same envs on
 // every step).  Speed only -- any placement is correct.
-__device__ __forceinline__ int64_t remap_block() {
-    const uint32_t nb = gridDim.x, b = blockIdx.x;
+__device__ __forceinline__ int64_t remap_block(uint32_t first = 0u) {
+    const uint32_t nb = gridDim.x - first, b = blockIdx.x - first;   // `first` leading workgroups have another role
     if ((nb & 7u) == 0u) return (int64_t)(b & 7u) * (nb >> 3) + (b >> 3);
     return b;
 }
@@ -378,11 +365,8 @@ __device__ __forceinline__ int64_t remap_block() {
 // ---- Philox4x32-10 counter-based reset RNG ---------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
-#ifndef ACAS2D_EXPERIMENT_PHILOX_ROUNDS
-#define ACAS2D_EXPERIMENT_PHILOX_ROUNDS 10      // diagnostic experiments only; 10 = Philox4x32-10
-#endif
 #pragma unroll
-    for (int r = 0; r < ACAS2D_EXPERIMENT_PHILOX_ROUNDS; ++r) {
+    for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;   // v_mad_u64_u32
         c = U4{(uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0};
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -450,11 +434,6 @@ template <typename T, bool FAST, bool ZERO_ACTION = false>
 __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T>& o) {
     OwnCtx<T> c;
     c.x = o.x; c.y = o.y; c.v = o.v;
-#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 1     // diagnostic: arithmetic stubbed out
-    c.co = o.psi; c.so = o.v; c.v1x = o.a_lat; c.v1y = o.gx; c.x1 = o.gy; c.y1 = p.dt;
-    c.d_goal = o.x + T(1000); c.h_goal = o.psi; c.d_dev = o.y;
-    return c;
-#endif
     if constexpr (FAST) {
         f_sincos_rev(o.psi * Const<T>::inv360, &c.so, &c.co);
         T s1 = c.so, c1 = c.co;
@@ -512,10 +491,6 @@ __device__ __forceinline__ void traffic_move(const Params<T>& p, bool move, T& t
 template <typename T, bool FAST>
 __device__ __forceinline__ void traffic_observe(const Params<T>& p, const OwnCtx<T>& c, T tx, T ty, T tv,
                                                 T st, T ct, T& d, T& dca, T& vc) {
-#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 1     // diagnostic: arithmetic stubbed out
-    d = tx + T(1000); dca = ty + c.v1x; vc = tv + st + c.x1 + c.y1 + c.v1y + ct;
-    return;
-#endif
     if constexpr (FAST) {
         const T tvdt = tv * p.dt;
         const T v2x = rounded(tvdt * ct), v2yt = tvdt * st;
@@ -625,10 +600,6 @@ __device__ __forceinline__ void put_own_obs(const Params<T>& p, T* row, int32_t 
 // game.py:205-210: the three normalised entries of one traffic aircraft into the LDS row.
 template <typename T, bool FAST>
 __device__ __forceinline__ void put_traffic_obs(const Params<T>& p, T* q, T d, T dca, T vc) {
-#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 3
-    asm volatile("" :: "v"(d), "v"(dca), "v"(vc));
-    return;
-#endif
     if constexpr (FAST) {
         q[0] = d * p.inv_d_sep_max; q[1] = dca * p.inv_d_cpa_max; q[2] = vc * p.inv_v_closing_max;
     } else {
@@ -659,15 +630,18 @@ __device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int i0)
 // Packed shapes get their traffic in registers (`tr`, loaded by the caller up front so that all
 // of a wave's loads are in flight together) and write the moved block back; the generic walk
 // loads / stores aircraft by aircraft.
-template <typename T, int C, int G, bool PACKED, bool FAST>
+// `after_own(c)` runs between the player side and the traffic side (the step kernel's pool fetch).
+struct NoHook { template <typename X> __device__ __forceinline__ void operator()(const X&) const {} };
+template <typename T, int C, int G, bool PACKED, bool FAST, typename Hook = NoHook>
 __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
                                            int e, int j, int N, int32_t steps, bool move,
                                            Traffic<T, C>& tr, T* __restrict__ row, bool store_traffic = true,
-                                           TrigCache<T, C>* tc = nullptr) {
+                                           TrigCache<T, C>* tc = nullptr, Hook after_own = Hook()) {
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
     // Keep the traffic arithmetic below this line: the player side above needs only the scalars, which
     // were requested first, so it runs under s_waitcnt vmcnt(11..5) while the traffic vectors land.
     if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
+    after_own(c);
     Seen<T> r;
     r.d_goal = c.d_goal; r.h_goal = c.h_goal; r.d_dev = c.d_dev;
     int coll = 0;
@@ -678,11 +652,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
         // Move the whole block first and store it at once: the state write-back (half of the
         // kernel's store bytes besides obs) then drains underneath the observation arithmetic
         // instead of joining the write burst at the end of the wave.
-#ifdef ACAS2D_ABLATE
-        constexpr bool PAIRS = false;                                    // the ablation stubs live in the scalar walk
-#else
-        constexpr bool PAIRS = FAST && sizeof(T) == 4 && C % 2 == 0;    // see traffic_move2()
-#endif
+        constexpr bool PAIRS = FAST && sizeof(T) == 4 && C % 2 == 0;    // see traffic_trig2() / traffic_observe2()
         bool psi_changed = false;
         T st[C], ct[C];
         if constexpr (PAIRS) {
@@ -721,12 +691,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
         }
         // rollout: a wrapped heading waits in registers for the last step's store
         if (tc != nullptr) { tc->dirty |= psi_changed; psi_changed = tc->dirty; }
-#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 5
-        asm volatile("" :: "v"(tr.x.v[0]), "v"(tr.y.v[0]));
-        if (false) {
-#else
         if (move && store_traffic) {
-#endif
 #if ACAS2D_OBS_STORE >= 2
             store_chunk<T, C>(reinterpret_cast<V*>(s.trf_x + i0), tr.x);
             store_chunk<T, C>(reinterpret_cast<V*>(s.trf_y + i0), tr.y);
@@ -785,74 +750,14 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
     return r;
 }
 
-// ACAS2DGame.__init__ reset distribution, game.py:80-116, from one Philox block per entity:
-// counter = (env_lo, env_hi, episode, entity) with entity 0 = player, 1 + n = traffic n;
-// words: x (bit 31 of it = starts_down for traffic 0), y, heading, airspeed factor.
-template <typename T>
-__device__ __forceinline__ void reset_traffic(const ResetParams& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
-                                              uint32_t g_hi, uint32_t episode, int n, T& ox, T& oy, T& opsi,
-                                              T& ov) {
-#pragma clang fp contract(off)
-    const U4 w = philox4x32_10(U4{g_lo, g_hi, episode, 1u + (uint32_t)n}, k0, k1);
-    double x, y, psi;
-    const double v = uniform(rp.speed_factor_min, rp.speed_factor_max, u01(w.w)) * rp.airspeed;
-    if (n == 0) {
-        const double down = (double)(w.x >> 31);
-        x = rp.t0_x;
-        y = rp.t0_y_base + (down * rp.t0_y_span);
-        psi = py_mod360(rp.t0_heading_base + (down * rp.t0_heading_step) +
-                        uniform(-rp.t0_heading_jitter, rp.t0_heading_jitter, u01(w.z)));
-    } else {
-        x = uniform(0.0, rp.tn_x_max, u01(w.x));
-        y = uniform(0.0, rp.tn_y_max, u01(w.y));
-        psi = uniform(0.0, 360.0, u01(w.z));
-    }
-    ox = (T)x; oy = (T)y; opsi = (T)psi; ov = (T)v;
-}
-
-template <typename T, int C, int G, bool PACKED>
-__device__ __forceinline__ Own<T> reset_env(const ResetParams& rp, const State<T>& s, uint32_t k0,
-                                            uint32_t k1, uint64_t gid, uint32_t episode, int e,
-                                            int j, int N, Traffic<T, C>& tr) {
-#pragma clang fp contract(off)   // float64 here in both builds: a seed names the same episode
-    const uint32_t g_lo = (uint32_t)gid, g_hi = (uint32_t)(gid >> 32);
-    const U4 w = philox4x32_10(U4{g_lo, g_hi, episode, 0u}, k0, k1);
-    Own<T> o;
-    o.x = (T)rp.own_x0;
-    o.y = (T)rp.own_y0;
-    o.v = (T)rp.own_v;
-    o.psi = (T)py_mod360(rp.own_heading0 + uniform(-rp.own_heading_jitter, rp.own_heading_jitter, u01(w.z)));
-    o.gx = (T)rp.goal_x;
-    o.gy = (T)rp.goal_y;
-    o.a_lat = T(0);
-    if constexpr (PACKED) {
-        using V = Vec<T, C>;
-#pragma unroll
-        for (int k = 0; k < C; ++k)
-            reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, j * C + k, tr.x.v[k], tr.y.v[k], tr.psi.v[k], tr.v.v[k]);
-        const int i0 = e * N + j * C;
-        *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
-        *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
-        *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;
-        *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
-    } else {
-        for (int n = j; n < N; n += G) {
-            const int i = e * N + n;
-            T x, y, psi, v;
-            reset_traffic<T>(rp, k0, k1, g_lo, g_hi, episode, n, x, y, psi, v);
-            s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = psi; s.trf_v[i] = v;
-        }
-    }
-    if (j == 0) {
-        s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi; s.own_v[e] = o.v;
-        s.goal_x[e] = o.gx; s.goal_y[e] = o.gy;
-    }
-    return o;
-}
-
-// Entity `ent` of a fresh episode from ONE Philox block: ent 0 = the player (only its heading is
-// random, returned in opsi; game.py:85-92), ent n + 1 = traffic n (game.py:96-116).  Bitwise the
-// same draws as reset_env() / reset_traffic().
+// ACAS2DGame.__init__ reset distribution, game.py:80-116, from one Philox block per ENTITY:
+// counter = (env_lo, env_hi, episode, entity) with entity 0 = the player (only its heading is random,
+// returned in opsi; game.py:85-92), entity n + 1 = traffic n (game.py:96-116); words: x (bit 31 of it =
+// starts_down for traffic 0), y, heading, airspeed factor.  The ONE formulation of the distribution per
+// element type: reset(), the in-step auto-reset and the episode pool all call it, so (seed, global env
+// index, episode counter) names the same episode bit for bit whichever path draws it.  float64 draws use
+// 32 random bits per uniform; the float32 build draws in float32 from 24 bits (equal to the float64
+// evaluation rounded to float32 up to 1-2 ulp, at a fraction of its latency).
 template <typename T, typename R>
 __device__ __forceinline__ void reset_entity(const ResetParamsT<R>& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
                                              uint32_t g_hi, uint32_t episode, int ent, T& ox, T& oy, T& opsi,
@@ -883,6 +788,41 @@ __device__ __forceinline__ void reset_entity(const ResetParamsT<R>& rp, uint32_t
     const double y = first ? (rp.t0_y_base + (down * rp.t0_y_span)) : uniform(0.0, rp.tn_y_max, u01(w.y));
     const double v = uniform(rp.speed_factor_min, rp.speed_factor_max, u01(w.w)) * rp.airspeed;
     ox = (T)x; oy = (T)y; opsi = (T)psi; ov = (T)v;
+}
+
+// reset() for one env by its owner group: lane j draws its own traffic aircraft (and, redundantly, the
+// player's heading), stores the new state and returns the player.
+template <typename T, int C, int G, bool PACKED, typename R>
+__device__ __forceinline__ Own<T> reset_env(const ResetParamsT<R>& rp, const State<T>& s, uint32_t k0,
+                                            uint32_t k1, uint64_t gid, uint32_t episode, int e,
+                                            int j, int N, Traffic<T, C>& tr) {
+    const uint32_t g_lo = (uint32_t)gid, g_hi = (uint32_t)(gid >> 32);
+    T ux, uy, psi_own, uv;
+    reset_entity<T, R>(rp, k0, k1, g_lo, g_hi, episode, 0, ux, uy, psi_own, uv);
+    const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+    if constexpr (PACKED) {
+        using V = Vec<T, C>;
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+            reset_entity<T, R>(rp, k0, k1, g_lo, g_hi, episode, 1 + j * C + k, tr.x.v[k], tr.y.v[k], tr.psi.v[k], tr.v.v[k]);
+        const int i0 = e * N + j * C;
+        *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
+        *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+        *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;
+        *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
+    } else {
+        for (int n = j; n < N; n += G) {
+            const int i = e * N + n;
+            T x, y, psi, v;
+            reset_entity<T, R>(rp, k0, k1, g_lo, g_hi, episode, n + 1, x, y, psi, v);
+            s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = psi; s.trf_v[i] = v;
+        }
+    }
+    if (j == 0) {
+        s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi; s.own_v[e] = o.v;
+        s.goal_x[e] = o.gx; s.goal_y[e] = o.gy;
+    }
+    return o;
 }
 
 // Wave-cooperative reset of ONE finished env inside the step kernel (SB3 DummyVecEnv.step_wait
@@ -1082,6 +1022,204 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
     return taken;
 }
 
+// ---- the episode pool (include/acas2d.h, Acas2dState.pool) ------------------------------------------
+// Re-initialising a finished env is ACAS2DGame.__init__ (game.py:80-116: one Philox block per aircraft)
+// plus the new episode's first observe(): ~1.2 us of dependent latency at the very END of the launch,
+// on the wave every other wave then waits for (the launch ends with its slowest wave; measured:
+// 5.8 us per launch with resets against 4.6 us when nothing ever finishes, 65 536 x 8).  The pool takes
+// that chain off the step.  Slot r & 1 of env e holds episode r -- traffic block, player heading, first
+// observation -- tagged with (r, key), for r = episode[e] + 1 and + 2.
+//   * a stepping wave tests, right after its loads, which of its envs CAN finish in this step
+//     (conservative: may_finish()) and fetches their next episode from the pool in the shadow of the
+//     arithmetic; a finished env whose fetched tag matches is re-initialised by register selects and one
+//     LDS row rewrite (pool commit), anything else falls back to the in-kernel generator below;
+//   * every reset posts ONE request: refill the slot just used (or skipped) with episode + 2.  That slot
+//     is not read again before the env's next-but-one finish, i.e. not in the next launch;
+//   * the first workgroups of the NEXT step launch are helper waves (pool_helper_wave): they scan the
+//     request bits, generate the requested episodes with the same per-entity functions as the in-kernel
+//     reset (same bits), store them and drop the requests -- off every stepping wave's path.
+// The pool is a cache: a stale or missing slot only costs the slow path.
+struct PoolArg {
+    unsigned char* base;      // nullptr = no pool
+    uint32_t epad;            // n_envs rounded up to a multiple of kPoolWindow
+    uint32_t key;             // hash of (seed, env_offset, reset distribution): slots of another key are stale
+    int32_t helper_blocks;    // leading workgroups of a step launch that refill slots
+    int32_t _pad;
+};
+constexpr int kPoolWindow = 256;     // envs scanned by one helper wave
+constexpr int kPoolHeader = 64;      // bytes
+
+template <typename T>
+struct PoolView {
+    unsigned char* base;
+    int64_t epad;
+    int N;
+    // byte offsets; every block is a multiple of 16 bytes because epad is a multiple of 256
+    __host__ __device__ int64_t off_req_ep() const { return kPoolHeader + (epad >> 2); }            // after 2 x epad/8
+    __host__ __device__ int64_t off_tag() const { return off_req_ep() + 8 * epad; }                 // after 2 x epad x 4
+    __host__ __device__ int64_t off_own_psi() const { return off_tag() + 16 * epad; }               // after 2 x epad x 8
+    __host__ __device__ int64_t off_trf() const { return off_own_psi() + 2 * epad * (int64_t)sizeof(T); }
+    __host__ __device__ int64_t off_obs() const { return off_trf() + 8 * epad * N * (int64_t)sizeof(T); }
+    __host__ __device__ int64_t bytes() const { return off_obs() + 2 * epad * (5 + 3 * (int64_t)N) * (int64_t)sizeof(T); }
+    // header: event counters (diagnostics / tests): [0] resets served from the pool, [1] resets generated
+    // inside the step although a pool is attached (stale / unfetched slot), [2] slots refilled by helper waves
+    __device__ __forceinline__ uint32_t* counters() const { return reinterpret_cast<uint32_t*>(base); }
+    __device__ __forceinline__ uint32_t* req_bits(int s) const { return reinterpret_cast<uint32_t*>(base + kPoolHeader) + s * (epad >> 5); }
+    __device__ __forceinline__ uint32_t* req_ep(int s) const { return reinterpret_cast<uint32_t*>(base + off_req_ep()) + s * epad; }
+    __device__ __forceinline__ uint2* tag(int s) const { return reinterpret_cast<uint2*>(base + off_tag()) + s * epad; }
+    __device__ __forceinline__ T* own_psi(int s) const { return reinterpret_cast<T*>(base + off_own_psi()) + s * epad; }
+    // field f = 0..3 (x, y, psi, v), env-major [epad][N] like the live traffic block
+    __device__ __forceinline__ T* trf(int f, int s) const { return reinterpret_cast<T*>(base + off_trf()) + (int64_t)(s * 4 + f) * epad * N; }
+    __device__ __forceinline__ T* obs(int s) const { return reinterpret_cast<T*>(base + off_obs()) + (int64_t)s * epad * (5 + 3 * N); }
+};
+
+// Episode `r` of env `e` (index within this shard) into slot r & 1, by the lanes of one reset slot
+// (ResetSlots<NS>: lane `ent` of the slot = entity `ent`, 0 the player, n + 1 traffic n) -- the per-lane
+// functions of wave_reset_slots(), so the pooled episode equals the one generated inside a step bit for
+// bit.  Whole wave; `have`, `e`, `r` are uniform within a slot.
+template <typename T, bool FAST, int NS, typename R>
+__device__ __forceinline__ void pool_generate(const Params<T>& p, const ResetParamsT<R>& rp, const PoolView<T>& pool,
+                                              uint32_t k0, uint32_t k1, uint32_t key, int64_t env_offset, bool have,
+                                              int e, uint32_t r, int lane) {
+    using RS = ResetSlots<NS>;
+    constexpr int N = NS, D = 5 + 3 * NS;
+    const int ent = lane % RS::STRIDE;
+    const int sl = (int)(r & 1u);
+    const uint64_t gid = (uint64_t)(env_offset + (int64_t)e);
+    T tx = T(0), ty = T(0), tpsi = T(0), tv = T(0);
+    const bool mine = have && ent <= N;
+    if (mine) reset_entity<T, R>(rp, k0, k1, (uint32_t)gid, (uint32_t)(gid >> 32), r, ent, tx, ty, tpsi, tv);
+    const T psi_own = __shfl(tpsi, lane & ~(RS::STRIDE - 1), 64);      // the slot's player heading
+    const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+    const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
+    if (mine) {
+        T* obs = pool.obs(sl) + (int64_t)e * D;
+        if (ent >= 1) {
+            const int64_t i = (int64_t)e * N + (ent - 1);
+            pool.trf(0, sl)[i] = tx; pool.trf(1, sl)[i] = ty; pool.trf(2, sl)[i] = tpsi; pool.trf(3, sl)[i] = tv;
+            T d, dca, vc;
+            traffic_step<T, FAST>(p, c, false, tx, ty, tpsi, tv, d, dca, vc);     // environment.py:44-48: first observe()
+            put_traffic_obs<T, FAST>(p, obs + 5 + 3 * (ent - 1), d, dca, vc);
+        } else {
+            pool.own_psi(sl)[e] = tpsi;
+            put_own_obs<T, FAST>(p, obs, 1, o.psi, c);
+            pool.tag(sl)[e] = make_uint2(r, key);
+        }
+    }
+}
+
+// One helper wave of a step launch: the refill requests of envs [hw * 256, hw * 256 + 256).
+template <typename T, bool FAST, int NS, typename R>
+__device__ __forceinline__ void pool_helper_wave(const Params<T>& p, const ResetParamsT<R>& rp, const PoolView<T>& pool,
+                                                 uint32_t k0, uint32_t k1, uint32_t key, int64_t env_offset,
+                                                 int64_t n_envs, int64_t hw, int lane) {
+    using RS = ResetSlots<NS>;
+    const int64_t w0 = hw * kPoolWindow;
+    if (w0 >= n_envs) return;
+    // request bits of the window: lanes 0..7 the eight words of slot 0, lanes 8..15 those of slot 1
+    uint32_t w = 0;
+    if (lane < 16) w = pool.req_bits(lane >> 3)[(w0 >> 5) + (lane & 7)];
+    unsigned long long m = __ballot(w != 0u);
+    const int slot = lane / RS::STRIDE;
+    while (m) {                                            // wave-uniform; almost always zero or one trip
+        int my_e = 0, my_s = 0;
+        bool have = false;
+        for (int k = 0; k < RS::SLOTS && m != 0; ++k) {    // reset slot k <- the next pending request
+            const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, L);
+            const int b = __ffs((int)wl) - 1;
+            wl &= wl - 1u;
+            if (lane == L) w = wl;
+            if (wl == 0u) m &= m - 1ull;
+            if (slot == k) { my_e = (int)w0 + ((L & 7) << 5) + b; my_s = L >> 3; have = true; }
+        }
+        uint32_t r = 0u;
+        if (have) r = pool.req_ep(my_s)[my_e];
+        // a request names its slot by the parity of its episode; anything else is debris and is dropped
+        const bool ok = have && r != 0u && (int)(r & 1u) == my_s && my_e < n_envs;
+        pool_generate<T, FAST, NS, R>(p, rp, pool, k0, k1, key, env_offset, ok, my_e, r, lane);
+        if (have && lane % RS::STRIDE == 0) {
+            pool.req_ep(my_s)[my_e] = 0u;
+            atomicAnd(&pool.req_bits(my_s)[my_e >> 5], ~(1u << (my_e & 31)));
+            if (ok) atomicAdd(pool.counters() + 2, 1u);
+        }
+    }
+}
+
+// Can this lane's traffic end the env's episode in THIS step?  Conservative: the player has already
+// moved (o.x, o.y), an aircraft still moves by exactly v dt (aircraft.py:24-25), so its distance after
+// the move is at least the distance now minus v dt; the slack covers every rounding on the way.  NaN
+// state compares false here exactly as in detect_collisions (game.py:185-189).
+template <typename T, int C>
+__device__ __forceinline__ bool may_collide(const Params<T>& p, const Own<T>& o, const Traffic<T, C>& tr) {
+    bool any = false;
+    const T dts = p.dt * T(1.0001), base = p.collision_dist + T(0.01);
+    if constexpr (sizeof(T) == 4 && C % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < C; k += 2) {
+            const F2 dx = F2{tr.x.v[k], tr.x.v[k + 1]} - o.x, dy = F2{tr.y.v[k], tr.y.v[k + 1]} - o.y;
+            const F2 thr = m_fma(F2{tr.v.v[k], tr.v.v[k + 1]}, F2{dts, dts}, F2{base, base});
+            const F2 d2 = m_fma(dy, dy, dx * dx), t2 = thr * thr;
+            any |= (d2.x < t2.x) | (d2.y < t2.y);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const T dx = tr.x.v[k] - o.x, dy = tr.y.v[k] - o.y;
+            const T thr = m_fma(tr.v.v[k], dts, base);
+            any |= m_fma(dy, dy, dx * dx) < thr * thr;
+        }
+    }
+    return any;
+}
+
+// What a stepping wave fetched from the pool for the envs that may finish in this step.
+constexpr int kPoolRows = 4;          // first observations prefetched per wave (more candidates: slow path)
+template <typename T, int C, int G, int NS>
+struct PoolFetch {
+    Traffic<T, C> tr;                 // owner lanes: their part of the next episode's traffic block
+    T own_psi;
+    uint32_t tag_ep, tag_key;
+    T row[kPoolRows];                 // lane i: entry i of the next first observation of candidate q
+    unsigned long long cm;            // candidate envs (bit = lane of the group leader)
+    bool cand;
+
+    __device__ __forceinline__ void fetch(const Params<T>& p, const PoolView<T>& pool, const Own<T>& o, const OwnCtx<T>& c,
+                                          const Traffic<T, C>& live, int32_t steps, uint32_t episode, int64_t e_wave,
+                                          int el, int j, int lane, bool active) {
+        constexpr int N = NS, D = 5 + 3 * NS;
+        using V = Vec<T, C>;
+        // game.py:294-314: timeout and goal are known exactly already, only the collision needs the bound
+        const bool mine = may_collide<T, C>(p, o, live) | (c.d_goal < p.goal_radius) | (steps > p.max_steps);
+        cand = active && group_or<G>((int)mine) != 0;
+        cm = __ballot(cand && j == 0);
+        tag_ep = 0u; tag_key = 0u; own_psi = T(0);
+        if (cm != 0) {                                     // wave-uniform: ~1 wave in 5 at 65 536 x 8
+            const int sl = (int)((episode + 1u) & 1u);     // the slot that holds episode + 1
+            if (cand) {
+                const int64_t e = e_wave + el, i0 = e * N + j * C;
+                tr.psi = *reinterpret_cast<const V*>(pool.trf(2, sl) + i0);
+                tr.v = *reinterpret_cast<const V*>(pool.trf(3, sl) + i0);
+                tr.x = *reinterpret_cast<const V*>(pool.trf(0, sl) + i0);
+                tr.y = *reinterpret_cast<const V*>(pool.trf(1, sl) + i0);
+                own_psi = pool.own_psi(sl)[e];
+                const uint2 tg = pool.tag(sl)[e];
+                tag_ep = tg.x; tag_key = tg.y;
+            }
+            unsigned long long rm = cm;
+#pragma unroll
+            for (int q = 0; q < kPoolRows; ++q) {
+                if (rm != 0) {
+                    const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)rm) - 1);
+                    rm &= rm - 1ull;
+                    const int sq = __builtin_amdgcn_readlane(sl, b);
+                    if (lane < D) row[q] = (pool.obs(sq) + (e_wave + b / G) * D)[lane];
+                }
+            }
+        }
+    }
+};
+
 // Flush the wave's LDS tile (`count` values, the contiguous slice dst[0 .. count) of obs[E][D])
 // with lane-linear stores: 16 bytes per lane where the slice is 16-byte aligned, else one value.
 // Chunk c (16 bytes, or one value on the unaligned path) is always written by lane c % 64, so a
@@ -1234,13 +1372,18 @@ __device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&
 // arithmetic is this same code, so rollout(T) == T x step() bit for bit.
 // With POLICY (rollout, one lane per env) the action of every step comes from policy_action() on the
 // previous observation instead of from actions[t][E], which becomes an output.
-template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false>
+// With POOL (per-step launch, packed shape, auto-reset) the first pk.helper_blocks workgroups refill the
+// episode pool and the stepping waves take finished envs' next episodes from it (see "the episode pool").
+template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false,
+          bool POOL = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
-                                                      int tile_elems, int n_steps, PolicyW pw) {
+                                                      int tile_elems, int n_steps, PolicyW pw, PoolArg pk) {
     static_assert(!ROLLOUT || (AUTO_RESET && PACKED), "rollout: auto-reset semantics, packed shapes");
     static_assert(!POLICY || (ROLLOUT && G == 1), "in-kernel policy: rollout mode, one lane per env");
+    static_assert(!POOL || (PACKED && AUTO_RESET && !ROLLOUT && ResetSlots<C * G>::SLOTS >= 2 && 5 + 3 * C * G <= 64),
+                  "episode pool: per-step launch, packed shape, auto-reset, N + 1 <= 32, obs row within a wave");
     constexpr int NS = PACKED ? C * G : 0;         // packed shapes: n_traffic is a compile-time constant
     const int N = PACKED ? NS : N_arg;
     constexpr int EPW = 64 / G;                    // envs per wavefront
@@ -1252,12 +1395,21 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         asm volatile("" :: "s"(nb), "s"(n_envs), "s"(s_arg.own_x), "s"(s_arg.own_y), "s"(s_arg.own_psi), "s"(s_arg.own_v),
                      "s"(s_arg.goal_x), "s"(s_arg.goal_y), "s"(s_arg.trf_x), "s"(s_arg.trf_y), "s"(s_arg.trf_psi),
                      "s"(s_arg.trf_v), "s"(s_arg.steps), "s"(s_arg.total_reward), "s"(s_arg.episode), "s"(io_arg.actions),
-                     "s"(tile_elems));
+                     "s"(tile_elems), "s"(pk.helper_blocks));
     }
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
     const int wib = wave_in_block();
-    const int64_t wave = remap_block() * kWavesPerBlock + wib;
+    const uint32_t helpers = POOL ? (uint32_t)pk.helper_blocks : 0u;
+    const PoolView<T> pool{pk.base, (int64_t)pk.epad, NS};
+    if constexpr (POOL) {
+        if (blockIdx.x < helpers) {                // this workgroup refills pool slots and steps nothing
+            pool_helper_wave<T, FAST, NS>(p_arg, rp, pool, k0, k1, pk.key, env_offset, n_envs,
+                                          (int64_t)blockIdx.x * kWavesPerBlock + wib, lane);
+            return;
+        }
+    }
+    const int64_t wave = remap_block(helpers) * kWavesPerBlock + wib;
     const int64_t e_wave = wave * EPW;             // first env of this wave (scalar)
     if (e_wave >= n_envs) return;                  // whole wave idle
     const int D = 5 + 3 * N;
@@ -1317,6 +1469,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                      "s"(k0), "s"(k1), "s"(io_arg.ep_steps));
     }
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
+    PoolFetch<T, C, G, NS> pf;                             // POOL only
+    pf.cm = 0; pf.cand = false;
     const int T_steps = ROLLOUT ? n_steps : 1;
     if constexpr (POLICY) {
         // the observation the first action is taken on (reset()'s / the previous step's) into the lane's row
@@ -1332,6 +1486,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                            io0.ep_steps ? io0.ep_steps + te : nullptr};
         const bool last = !ROLLOUT || t == T_steps - 1;
         uint8_t oc = 0;
+        T rw_out = T(0);
         T action = action_next;
         if constexpr (POLICY) {
             constexpr int DP = 5 + 3 * NS;                // compile-time obs width (packed shapes)
@@ -1373,8 +1528,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // `episode` is first USED in the reset loop far below; without this use the compiler waits
             // for its load there with s_waitcnt vmcnt(0) -- i.e. for every store issued since.
             asm volatile("" : "+v"(episode));
+            // POOL: between the player side and the traffic side, fetch the next episodes of the envs that may finish
+            auto pool_fetch = [&](const OwnCtx<T>& c) {
+                if constexpr (POOL) pf.fetch(p, pool, o, c, tr, steps, episode, e_wave, el, j, lane, active);
+            };
             Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
-                                                       ROLLOUT ? &trig : nullptr);
+                                                       ROLLOUT ? &trig : nullptr, pool_fetch);
 
             // game.py:249-292 evaluate()
             T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
@@ -1387,15 +1546,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
             total = total + rw;                                               // :287
             if (!active) oc = 0;                          // a padding lane never finishes anything
-#if defined(ACAS2D_ABLATE) && ACAS2D_ABLATE >= 4
-            asm volatile("" :: "v"(rw), "v"(o.x), "v"(o.y), "v"(o.psi));
-            if (false) {
-#else
+            rw_out = rw;
             if (j == 0 && active) {
-#endif
-                io.reward[el] = rw;
-                io.done[el] = oc != 0;
-                io.outcome[el] = oc;
+                if constexpr (!POOL) {                    // (POOL: stored behind the pool commit, see there)
+                    io.reward[el] = rw;
+                    io.done[el] = oc != 0;
+                    io.outcome[el] = oc;
+                }
                 if constexpr (!HANDOFF) {
                     if (last && (oc == 0 || !AUTO_RESET)) {
                         s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
@@ -1418,6 +1575,68 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // row: 0.8 us of the 7.7 us launch at 65 536 x 8.)
             bool fresh = false;
             unsigned long long dm = __ballot(oc != 0 && j == 0);
+            if constexpr (POOL) {
+                // ---- pool commit: a finished env whose next episode was fetched (right tag) takes it by
+                // register selects; its row of the tile is swapped for the fetched first observation.
+                if ((dm & pf.cm) != 0) {
+                    const int rank = __popcll(pf.cm & ((1ull << (el * G)) - 1ull));      // my env among the candidates
+                    const bool fast = oc != 0 && pf.cand && rank < kPoolRows && pf.tag_ep == episode + 1u && pf.tag_key == pk.key;
+                    const unsigned long long fm = __ballot(fast && j == 0);
+                    if (fm != 0) {
+                        // one wait for everything fetched, here: the only younger memory operations are the
+                        // traffic-block stores issued early in observe() (the per-env outputs follow below)
+#pragma unroll
+                        for (int q = 0; q < kPoolRows; ++q) asm volatile("" : "+v"(pf.row[q]));
+                        wave_lds_fence();                 // every row of the tile is complete
+                        unsigned long long rm = pf.cm;
+#pragma unroll
+                        for (int q = 0; q < kPoolRows; ++q) {
+                            if (rm != 0) {
+                                const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)rm) - 1);
+                                rm &= rm - 1ull;
+                                if ((fm >> b) & 1ull) {
+                                    T* rq = tile + (b / G) * D;
+                                    if (lane < D) {
+                                        const T last_obs = rq[lane];
+                                        if (io.term_obs) (io.term_obs + (b / G) * D)[lane] = last_obs;
+                                        rq[lane] = pf.row[q];                 // environment.py:44-48: the new episode's first observation
+                                    }
+                                }
+                            }
+                        }
+                        wave_lds_fence();                 // the fresh rows are complete
+                        if (fast) {
+                            if (j == 0) {
+                                if (io.ep_return) io.ep_return[el] = total;
+                                if (io.ep_steps) io.ep_steps[el] = steps;
+                            }
+                            tr = pf.tr;
+                            o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, pf.own_psi, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+                            steps = 1;                                            // environment.py:47
+                            total = T(0);
+                            episode += 1u;
+                            fresh = true;
+                            using V = Vec<T, C>;
+                            const int i0 = el * N + j * C;
+                            *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+                            *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
+                        }
+                        dm &= ~fm;
+                        if (lane == 0) atomicAdd(pool.counters() + 0, (uint32_t)__popcll(fm));
+                    }
+                }
+                if (dm != 0 && lane == 0) atomicAdd(pool.counters() + 1, (uint32_t)__popcll(dm));
+            }
+            if constexpr (POOL) {
+                // reward / done / outcome leave only now: issued before the commit they would stand between the
+                // pool loads and their wait (vmcnt retires in order), and the commit would wait for their
+                // acknowledgements
+                if (j == 0 && active) {
+                    io.reward[el] = rw_out;
+                    io.done[el] = oc != 0;
+                    io.outcome[el] = oc;
+                }
+            }
             constexpr bool SLOTTED = ResetSlots<NS>::SLOTS >= 2;      // N + 1 <= 32: several envs per pass
             if constexpr (SLOTTED) {
                 while (dm) {
@@ -1492,6 +1711,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                 if (fresh) {                              // per-episode constants of the new episode
                     s.episode[el] = episode;
                     s.own_v[el] = o.v; s.goal_x[el] = o.gx; s.goal_y[el] = o.gy;
+                    if constexpr (POOL) {
+                        // the slot this reset used (or found stale) held episode `episode`; it is next read at this
+                        // env's next-but-one finish: ask the next launch's helper waves to put episode + 2 there
+                        const int64_t e = e_wave + el;
+                        pool.req_ep((int)(episode & 1u))[e] = episode + 2u;
+                        atomicOr(&pool.req_bits((int)(episode & 1u))[e >> 5], 1u << (e & 31));
+                    }
                 }
                 if (last || fresh) {
                     s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
@@ -1502,14 +1728,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         }
         // Flush the tile (generic walk: now, the stores drain while finished envs are reset below).
         wave_lds_fence();
-#if !defined(ACAS2D_ABLATE) || ACAS2D_ABLATE < 2
         if constexpr (PACKED) {
             constexpr int kChunks = (EPW * (5 + 3 * NS) * (int)sizeof(T) / 16 + 63) / 64;
             flush_tile_unrolled<T, kChunks>(tile, obs_wave, n_rows * D, lane);
         } else {
             flush_tile<T>(tile, obs_wave, n_rows * D, lane);
         }
-#endif
         if (t == 0) ACAS2D_STAMP(4, wave, lane, false);
         if constexpr (AUTO_RESET && !HANDOFF) {
             // ---- generic walk: finished envs are reset by the whole wave, entity lanes store the new
@@ -1533,52 +1757,88 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     ACAS2D_STAMP(7, wave, lane, false);
 }
 
-// ACAS2DEnv.reset(), environment.py:44-48.
-template <typename T, int C, int G, bool PACKED, bool FAST>
+// ACAS2DEnv.reset(), environment.py:44-48 (do_init > 0: fresh episodes; == 0: keep the injected state;
+// < 0: leave the state alone), then -- POOL -- the pool slots of the selected envs for episode + 1, + 2.
+template <typename T, int C, int G, bool PACKED, bool FAST, bool POOL>
 __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams rp, State<T> s_arg,
                                                        const uint8_t* __restrict__ mask, T* obs,
                                                        int do_init, uint32_t k0, uint32_t k1,
                                                        int64_t env_offset, int64_t n_envs, int N,
-                                                       int tile_elems) {
+                                                       int tile_elems, PoolArg pk) {
     constexpr int EPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;
     const int wib = wave_in_block();
     const int64_t e_wave = (remap_block() * kWavesPerBlock + wib) * EPW;
-    if (e_wave + el >= n_envs) return;
+    if (e_wave >= n_envs) return;                          // whole wave idle
     const int D = 5 + 3 * N;
     const State<T> s = rebase(s_arg, e_wave, N);
-    if (mask && !mask[e_wave + el]) return;
+    const bool selected = e_wave + el < n_envs && (!mask || mask[e_wave + el]);
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T* row = reinterpret_cast<T*>(lds_raw) + wib * tile_elems + el * D;
-    Own<T> o;
-    Traffic<T, C> tr;
-    int32_t steps;
-    if (do_init) {
-        o = reset_env<T, C, G, PACKED>(rp, s, k0, k1, (uint64_t)(env_offset + e_wave + el), s.episode[el], el, j, N, tr);
-        steps = 0;
-    } else {
-        if constexpr (PACKED) tr = load_traffic<T, C>(s, el * N + j * C);
-        o = Own<T>{s.own_x[el], s.own_y[el], s.own_psi[el], s.own_v[el], T(0), s.goal_x[el], s.goal_y[el]};
-        steps = s.steps[el];
+    if (selected && do_init >= 0) {
+        Own<T> o;
+        Traffic<T, C> tr;
+        int32_t steps;
+        if (do_init) {
+            o = reset_env<T, C, G, PACKED>(rp, s, k0, k1, (uint64_t)(env_offset + e_wave + el), s.episode[el], el, j, N, tr);
+            steps = 0;
+        } else {
+            if constexpr (PACKED) tr = load_traffic<T, C>(s, el * N + j * C);
+            o = Own<T>{s.own_x[el], s.own_y[el], s.own_psi[el], s.own_v[el], T(0), s.goal_x[el], s.goal_y[el]};
+            steps = s.steps[el];
+        }
+        if (obs) {
+            steps += 1;
+            observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row);
+            wave_lds_fence();
+            T* dst = obs + (e_wave + el) * D;             // masked rows are not contiguous: per-row copy
+            for (int i = j; i < D; i += G) dst[i] = row[i];
+        }
+        if (j == 0) {
+            s.steps[el] = steps;
+            s.total_reward[el] = T(0);
+            s.status[el] = 0;
+        }
     }
-    if (obs) {
-        steps += 1;
-        observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row);
-        wave_lds_fence();
-        T* dst = obs + (e_wave + el) * D;             // masked rows are not contiguous: per-row copy
-        for (int i = j; i < D; i += G) dst[i] = row[i];
-    }
-    if (j == 0) {
-        s.steps[el] = steps;
-        s.total_reward[el] = T(0);
-        s.status[el] = 0;
+    if constexpr (POOL) {
+        if (pk.base != nullptr) {                          // whole wave from here on
+            constexpr int NS = C * G;
+            using RS = ResetSlots<NS>;
+            const PoolView<T> pool{pk.base, (int64_t)pk.epad, NS};
+            const uint32_t ep = selected ? s.episode[el] : 0u;
+            if (selected && j == 0) {                      // pending refill requests of these envs are void now
+                const int64_t e = e_wave + el;
+                pool.req_ep(0)[e] = 0u; pool.req_ep(1)[e] = 0u;
+                atomicAnd(&pool.req_bits(0)[e >> 5], ~(1u << (e & 31)));
+                atomicAnd(&pool.req_bits(1)[e >> 5], ~(1u << (e & 31)));
+            }
+            unsigned long long sel = __ballot(selected && j == 0);
+            const int slot = lane / RS::STRIDE;
+            while (sel != 0) {                             // SLOTS envs per pass, two episodes each
+                int my_el = 0;
+                uint32_t my_ep = 0u;
+                bool have = false;
+                for (int k = 0; k < RS::SLOTS && sel != 0; ++k) {
+                    const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)sel) - 1);
+                    sel &= sel - 1ull;
+                    const uint32_t ep_b = (uint32_t)__builtin_amdgcn_readlane((int)ep, b);
+                    if (slot == k) { my_el = b / G; my_ep = ep_b; have = true; }
+                }
+                pool_generate<T, FAST, NS>(p, rp, pool, k0, k1, pk.key, env_offset, have, (int)e_wave + my_el, my_ep + 1u, lane);
+                pool_generate<T, FAST, NS>(p, rp, pool, k0, k1, pk.key, env_offset, have, (int)e_wave + my_el, my_ep + 2u, lane);
+            }
+        }
     }
 }
 
 // ---- host-side launchers (instantiated per element type in acas2d_f32.hip / acas2d_f64.hip) ----
 struct Shape { int C, G; bool packed; };
 Shape choose_shape(int n_traffic, int elem_size);
+// shapes whose step kernel has a pooled variant (must agree with step_kernel's static_assert)
+constexpr bool pool_shape_ok(int C, int G, bool packed) {
+    return packed && C * G + 1 <= 32 && 5 + 3 * C * G <= 64;
+}
 
 template <typename T>
 int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, uint32_t flags,

@@ -87,12 +87,15 @@ class ACAS2DVecEnv:
                    episode counter) only, never on how the envs are sharded
     auto_reset     VecEnv semantics (True) or the single-env "latch the outcome, freeze the
                    traffic" semantics of the reference (False; game.py:243-245)
+    episode_pool   keep the next two episodes of every env pre-generated in HBM (include/acas2d.h,
+                   Acas2dState.pool) so that re-initialising a finished env does not sit at the end of
+                   the step launch; a cache -- results are bit-identical with and without it
     """
 
     metadata = {"render.modes": []}
 
     def __init__(self, num_envs, n_traffic=1, device="cuda", dtype=torch.float32, seed=13,
-                 env_offset=0, auto_reset=True, keep_terminal_obs=True, config=None):
+                 env_offset=0, auto_reset=True, keep_terminal_obs=True, config=None, episode_pool=True):
         if config is None:
             config = ACAS2DConfig(n_traffic=n_traffic)
         self.config = config
@@ -124,6 +127,8 @@ class ACAS2DVecEnv:
         self.total_reward = z(E)
         self.status = z(E, dt=torch.uint8)
         self.episode = z(E, dt=torch.int32)            # bit pattern of the u32 counter
+        nbytes = native.pool_bytes(E, N, 4 if dtype == torch.float32 else 8) if (episode_pool and auto_reset) else 0
+        self.pool = torch.zeros(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
         self._actions = z(E)
         self._obs = z(E, D)
         self._reward = z(E)
@@ -158,9 +163,26 @@ class ACAS2DVecEnv:
             self.env_offset, self.num_envs, self.n_traffic, self._stream()))
 
     # ---- gym / VecEnv surface -------------------------------------------------------------------
+    def refresh_pool(self):
+        """Rebuild the episode pool from the current episode counters (after anything but step() /
+        reset*() changed them: a fused rollout, a restored checkpoint, another seed)."""
+        if self.pool is not None:
+            with torch.cuda.device(self.device):
+                self._launch_reset(None, do_init=-1, with_obs=False)
+
+    def pool_counters(self):
+        """Diagnostics: {"pool": resets served from the episode pool, "in_step": resets generated inside
+        the step although a pool is attached (stale or unfetched slot), "refilled": slots refilled by the
+        helper waves} since construction; None without a pool."""
+        if self.pool is None:
+            return None
+        c = self.pool[:12].view(torch.int32).cpu().tolist()
+        return {"pool": c[0], "in_step": c[1], "refilled": c[2]}
+
     def seed(self, seed=None):
-        if seed is not None:
+        if seed is not None and int(seed) != self.seed_value:
             self.seed_value = int(seed)
+            self.refresh_pool()
         return [self.seed_value + i for i in range(min(self.num_envs, 16))]
 
     def reset(self):
@@ -286,6 +308,7 @@ class ACAS2DVecEnv:
             native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), T, self.seed_value,
                             self.env_offset, E, self.n_traffic, self._stream()))
             self._obs.copy_(out["obs"][T - 1])        # outputs["obs"] stays "the latest observation"
+            self.refresh_pool()                       # the rollout kernels do not maintain the episode pool
         out["_actions"] = a          # keep the (possibly re-laid-out) input alive until the launch ran
         return out
 
@@ -330,6 +353,7 @@ class ACAS2DVecEnv:
             native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), C.byref(pol), ptr(self._obs),
                             T, self.seed_value, self.env_offset, E, self.n_traffic, self._stream()))
             self._obs.copy_(out["obs"][T - 1])        # the observation the NEXT action would be taken on
+            self.refresh_pool()                       # the rollout kernels do not maintain the episode pool
         out["_weights"] = keep       # keep the transposed copies alive until the launch ran
         return out
 
@@ -358,7 +382,9 @@ class ACAS2DVecEnv:
         setattr(self, attr_name, value)
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
-        return [getattr(self, method_name)(*args, **kwargs)]
+        """SB3 VecEnv.env_method: one result per selected env (the call itself acts on the batch once)."""
+        n = self.num_envs if indices is None else len(list(indices))
+        return [getattr(self, method_name)(*args, **kwargs)] * n
 
     def env_is_wrapped(self, wrapper_class, indices=None):
         n = self.num_envs if indices is None else len(list(indices))
@@ -372,6 +398,7 @@ class ACAS2DVecEnv:
     def load_state_dict(self, sd):
         for n, v in sd.items():
             getattr(self, n).copy_(v)
+        self.refresh_pool()
 
     def algorithmic_bytes_per_step(self):
         s = 4 if self.dtype == torch.float32 else 8

@@ -29,6 +29,9 @@
  *                                                    (game.running/outcome, game.py:36,39)
  *   episode                                u32[E]    reset counter (input of the reset RNG)
  *   actions T[E]; obs T[E][D] row-major; reward T[E]; done u8[E]; outcome u8[E]
+ *   pool                                   bytes     optional episode pool (acas2d_pool_bytes()): the next two
+ *                                                    episodes of every env, pre-generated -- a cache of the
+ *                                                    reset distribution (game.py:80-116), see Acas2dState
  */
 #ifndef ACAS2D_H
 #define ACAS2D_H
@@ -40,7 +43,7 @@
 extern "C" {
 #endif
 
-#define ACAS2D_ABI_VERSION 2
+#define ACAS2D_ABI_VERSION 3
 
 /* error codes */
 #define ACAS2D_OK 0
@@ -96,6 +99,21 @@ typedef struct Acas2dState {
     void *total_reward;
     uint8_t *status;
     uint32_t *episode;
+    /* Optional (NULL = off).  The episode pool: acas2d_pool_bytes() bytes, 16-byte aligned, owned by the
+     * caller like every other buffer and private to this state (one pool per Acas2dState).  With
+     * ACAS2D_AUTO_RESET a finished env needs ACAS2DGame.__init__ (game.py:80-116: one RNG block per
+     * aircraft) plus the new episode's first observe() before its step can return -- a long dependent
+     * chain at the very end of the launch.  With a pool that chain is taken off the step: slot r & 1 of
+     * env e holds episode r (state + first observation, tagged with r and the RNG key) for r = episode[e]
+     * + 1, + 2; a finishing env takes its next episode from the pool (fetched early, by a conservative
+     * "can this env finish in this step" test on the loaded state) and posts a request; dedicated waves
+     * of the NEXT acas2d_step_* launch refill the slot.  A pure cache: results are bit-identical with and
+     * without it, and a slot whose tag does not match (pool not prepared, episode[] edited by the caller,
+     * another seed) is ignored -- the env is then re-initialised inside the step as without a pool.
+     * acas2d_reset_* prepares the slots of the envs it resets; acas2d_rollout_* neither reads nor
+     * maintains the pool: call acas2d_reset_*(do_init = -1) after a rollout (or after writing episode[])
+     * before the next acas2d_step_*.  Used by acas2d_step_* for packed work shapes with n_traffic <= 19. */
+    void *pool;
 } Acas2dState;
 
 /* Inputs / outputs of one step, device pointers.  term_obs, ep_return, ep_steps may be NULL. */
@@ -113,6 +131,11 @@ typedef struct Acas2dStepIO {
 
 int acas2d_abi_version(void);
 size_t acas2d_config_size(void);      /* sizeof(Acas2dConfig): layout check for bindings */
+size_t acas2d_state_size(void);       /* sizeof(Acas2dState) */
+
+/* Bytes of the episode pool for (n_envs, n_traffic, elem_size = 4 | 8); 0 when the configuration has
+ * no pooled step kernel (the caller then leaves Acas2dState.pool NULL). */
+size_t acas2d_pool_bytes(int64_t n_envs, int32_t n_traffic, int32_t elem_size);
 const char *acas2d_last_error(void);  /* thread-local; valid until the next failing call  */
 
 /*
@@ -188,6 +211,9 @@ int acas2d_rollout_policy_f64(const Acas2dConfig *cfg, const Acas2dState *state,
  *   do_init == 0: keep the state the caller wrote into the buffers (oracle-state injection /
  *                 host-side MT19937 "parity reset"), only zero total_reward and status;
  * then, if obs != NULL, run observe(): steps += 1 and the first observation into obs[e].
+ *   do_init  < 0: touch nothing of the state and write no observation; only (re)build the pool slots.
+ * In every mode, if state->pool != NULL, the pool slots of the selected envs are generated for
+ * episode[e] + 1 and + 2 and their pending refill requests are dropped.
  */
 int acas2d_reset_f32(const Acas2dConfig *cfg, const Acas2dState *state, const uint8_t *mask,
                      void *obs, int32_t do_init, uint64_t seed, int64_t env_offset,
