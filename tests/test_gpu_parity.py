@@ -448,35 +448,50 @@ def test_f32_statistical_single_step_vs_f64_oracle(g, O):
 
 
 def test_f32_reset_names_the_same_episodes(g, O):
-    """Same seed -> same episodes in both modes.  reset() (reset_kernel) evaluates the draws in
-    float64 and rounds once: bit-equal to the rounded oracle.  The in-step auto-reset of the
-    float32 build evaluates them in float32 (24 random bits): equal up to float32 rounding of
-    the 1600-px / 360-degree ranges (positions 2.5e-4, headings 6e-5)."""
+    """(seed, global env index, episode counter) names ONE episode per element type, whichever path draws
+    it: reset() / reset_masked() (reset_kernel), the auto-reset inside a step and the episode pool all call
+    the same per-entity function.  The float32 build evaluates the draws in float32 (24 random bits):
+    equal to the float64 oracle up to float32 rounding of the 1600-px / 360-degree ranges (positions
+    2.5e-4, headings 6e-5); the float64 build is bit-equal to the oracle (test_f64_auto_reset_vs_oracle)."""
     E, N = 4096, 8
     ref = O.OracleEnvs(E, N, seed=5, auto_reset=True)
     ref.reset()
-    env = GpuEngine(g, E, N, dtype=torch.float32, auto_reset=True, seed=5)
-    env.reset()
-    for name in ("own_psi", "trf_x", "trf_y", "trf_psi", "trf_v"):
-        assert np.array_equal(getattr(env, name), getattr(ref, name).astype(np.float32).astype(np.float64)), name
-    # step both with the same actions until plenty of envs have been reset inside the step
-    rng = np.random.default_rng(3)
-    checked = 0
-    for _ in range(40):
-        a = rng.uniform(-1, 1, E).astype(np.float32).astype(np.float64)
-        _, _, d1, _, _ = ref.step(a)
-        _, _, d2, _, _ = env.step(a)
-        both = (d1 != 0) & (d2 != 0) & (env.episode == ref.episode)
-        if both.any():
-            checked += int(both.sum())
-            assert np.abs(env.trf_x[both] - ref.trf_x[both]).max() < 2.5e-4
-            assert np.abs(env.trf_y[both] - ref.trf_y[both]).max() < 2.5e-4
-            dpsi = np.abs(env.trf_psi[both] - ref.trf_psi[both])
-            assert np.minimum(dpsi, 360 - dpsi).max() < 6e-5
-            dpsi = np.abs(env.own_psi[both] - ref.own_psi[both])
-            assert np.minimum(dpsi, 360 - dpsi).max() < 6e-5
-            assert np.array_equal(env.trf_v[both], ref.trf_v[both])
-    assert checked > 50
+
+    def close_to_oracle(env, sel):
+        assert np.abs(env.trf_x[sel] - ref.trf_x[sel]).max() < 2.5e-4
+        assert np.abs(env.trf_y[sel] - ref.trf_y[sel]).max() < 2.5e-4
+        for name in ("trf_psi", "own_psi"):
+            dpsi = np.abs(getattr(env, name)[sel] - getattr(ref, name)[sel])
+            assert np.minimum(dpsi, 360 - dpsi).max() < 6e-5, name
+        assert np.array_equal(env.trf_v[sel], ref.trf_v[sel])
+
+    for pool in (True, False):
+        env = GpuEngine(g, E, N, dtype=torch.float32, auto_reset=True, seed=5)
+        if not pool:
+            env.v = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, auto_reset=True, seed=5, episode_pool=False)
+        env.reset()
+        close_to_oracle(env, np.ones(E, bool))
+        # step both with the same actions until plenty of envs have been reset inside the step
+        rng = np.random.default_rng(3)
+        checked = 0
+        twin = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, auto_reset=True, seed=5, episode_pool=False)
+        for _ in range(40):
+            a = rng.uniform(-1, 1, E).astype(np.float32).astype(np.float64)
+            _, _, d1, _, _ = ref.step(a)
+            _, _, d2, _, _ = env.step(a)
+            both = (d1 != 0) & (d2 != 0) & (env.episode == ref.episode)
+            if both.any():
+                checked += int(both.sum())
+                close_to_oracle(env, both)
+            fresh = torch.as_tensor(d2 != 0, device="cuda:0")
+            if fresh.any():
+                # the same episodes drawn by reset_kernel on a twin env: bit for bit what the step produced
+                twin.episode.copy_(env.v.episode)
+                twin._launch_reset(fresh.to(torch.uint8), do_init=1)
+                for name in ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi", "trf_v"):
+                    assert torch.equal(getattr(twin, name)[fresh], getattr(env.v, name)[fresh]), (pool, name)
+                assert torch.equal(twin.outputs["obs"][fresh], env.v.outputs["obs"][fresh]), pool
+        assert checked > 50
 
 
 @pytest.mark.parametrize("dtype_name,N,E,T", (("float32", 8, 4096, 160), ("float64", 8, 1024, 120), ("float32", 64, 512, 40),
