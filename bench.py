@@ -76,6 +76,8 @@ def parse(argv=None):
                          "timeout only and resets are rare -- isolates the step itself at large N_TRAFFIC")
     ap.add_argument("--no-pool", action="store_true",
                     help="A/B: without the episode pool (finished envs are re-initialised inside the step launch)")
+    ap.add_argument("--pool-stats", action="store_true",
+                    help="diagnostic: count pool hits / in-step resets / refills (atomics on the reset paths)")
     ap.add_argument("--no-terminations", action="store_true",
                     help="diagnostic: no collisions, no goal, no timeout -- nothing ever finishes (the reset-free floor)")
     return ap.parse_args(argv)
@@ -287,6 +289,8 @@ class RehearsalEnv:
 
 def main():
     args = parse()
+    if args.pool_stats:
+        os.environ["ACAS2D_POOL_STATS"] = "1"
     world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if world_env == 0 and args.gpus > 1:
         sys.exit(self_launch(args.gpus))

@@ -44,6 +44,9 @@ namespace acas2d {
 constexpr int kBlock = ACAS2D_BLOCK;      // threads per workgroup (tuning knob; 256 measured best)
 constexpr int kWavesPerBlock = kBlock / 64;
 
+// constant address space: wave-uniform loads through it are scalar loads (s_load_*)
+#define ACAS2D_AS4 __attribute__((address_space(4)))
+
 #include "acas2d_diag.hpp"   // ACAS2D_STAMP(): empty in the product build
 
 // ---- launch-constant parameters, already rounded to T on the host -----------------------------
@@ -1044,10 +1047,26 @@ struct PoolArg {
     uint32_t epad;            // n_envs rounded up to a multiple of kPoolWindow
     uint32_t key;             // hash of (seed, env_offset, reset distribution): slots of another key are stale
     int32_t helper_blocks;    // leading workgroups of a step launch that refill slots
-    int32_t _pad;
+    uint32_t flags;           // bit 0: count events in the header (diagnostics / tests)
 };
 constexpr int kPoolWindow = 256;     // envs scanned by one helper wave
-constexpr int kPoolHeader = 64;      // bytes
+constexpr int kPoolHeader = 512;     // bytes
+
+// The pool's first bytes.  Written by reset_kernel (which has every launch constant) and read by the helper
+// waves of the step kernels with scalar loads INSIDE their own branch: a helper wave needs the launch
+// constants, the reset distribution and the RNG key, and as ordinary kernel arguments those were hoisted into
+// the entry block of the stepping waves too -- 46 SGPR spills and two more scalar-load round trips in front
+// of every wave's first global load (measured: +1.0 us per launch at 65 536 x 8).
+template <typename T>
+struct PoolHeader {
+    uint32_t counters[4];     // [0] resets served from the pool, [1] resets generated inside a step although a
+                              // pool is attached, [2] slots refilled by helper waves (only with PoolArg.flags & 1)
+    uint32_t key, k0, k1, n_traffic;
+    int64_t env_offset, n_envs;
+    Params<T> p;
+    ResetParamsT<T> rp;
+};
+static_assert(sizeof(PoolHeader<double>) <= kPoolHeader && sizeof(PoolHeader<float>) <= kPoolHeader, "pool header");
 
 template <typename T>
 struct PoolView {
@@ -1061,10 +1080,12 @@ struct PoolView {
     __host__ __device__ int64_t off_trf() const { return off_own_psi() + 2 * epad * (int64_t)sizeof(T); }
     __host__ __device__ int64_t off_obs() const { return off_trf() + 8 * epad * N * (int64_t)sizeof(T); }
     __host__ __device__ int64_t bytes() const { return off_obs() + 2 * epad * (5 + 3 * (int64_t)N) * (int64_t)sizeof(T); }
-    // header: event counters (diagnostics / tests): [0] resets served from the pool, [1] resets generated
-    // inside the step although a pool is attached (stale / unfetched slot), [2] slots refilled by helper waves
+    __device__ __forceinline__ PoolHeader<T>* header() const { return reinterpret_cast<PoolHeader<T>*>(base); }
     __device__ __forceinline__ uint32_t* counters() const { return reinterpret_cast<uint32_t*>(base); }
-    __device__ __forceinline__ uint32_t* req_bits(int s) const { return reinterpret_cast<uint32_t*>(base + kPoolHeader) + s * (epad >> 5); }
+    // request bits: per window of 256 envs sixteen words, slot 0's eight then slot 1's (one s_load_dwordx16)
+    __device__ __forceinline__ uint32_t* req_word(int s, int64_t e) const {
+        return reinterpret_cast<uint32_t*>(base + kPoolHeader) + ((e >> 8) * 16 + s * 8 + ((e >> 5) & 7));
+    }
     __device__ __forceinline__ uint32_t* req_ep(int s) const { return reinterpret_cast<uint32_t*>(base + off_req_ep()) + s * epad; }
     __device__ __forceinline__ uint2* tag(int s) const { return reinterpret_cast<uint2*>(base + off_tag()) + s * epad; }
     __device__ __forceinline__ T* own_psi(int s) const { return reinterpret_cast<T*>(base + off_own_psi()) + s * epad; }
@@ -1108,21 +1129,43 @@ __device__ __forceinline__ void pool_generate(const Params<T>& p, const ResetPar
     }
 }
 
-// One helper wave of a step launch: the refill requests of envs [hw * 256, hw * 256 + 256).
-template <typename T, bool FAST, int NS, typename R>
-__device__ __forceinline__ void pool_helper_wave(const Params<T>& p, const ResetParamsT<R>& rp, const PoolView<T>& pool,
-                                                 uint32_t k0, uint32_t k1, uint32_t key, int64_t env_offset,
-                                                 int64_t n_envs, int64_t hw, int lane) {
+// A struct of 4-byte-aligned members out of the constant address space, dword by dword (scalar loads).
+template <typename S>
+__device__ __forceinline__ S load_const(const S ACAS2D_AS4* src) {
+    static_assert(sizeof(S) % 4 == 0, "dword-sized struct");
+    union { S s; uint32_t w[sizeof(S) / 4]; } u;
+    const uint32_t ACAS2D_AS4* sp = (const uint32_t ACAS2D_AS4*)src;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(S) / 4; ++i) u.w[i] = sp[i];
+    return u.s;
+}
+
+// One helper wave of a step launch: the refill requests of envs [hw * 256, hw * 256 + 256).  Everything it
+// needs comes from the pool itself by scalar loads (header, request words), which do not queue behind the
+// chip-wide burst of vector loads the stepping waves start the launch with.
+template <typename T, bool FAST, int NS>
+__device__ __forceinline__ void pool_helper_wave(unsigned char* base, uint32_t epad, uint32_t key, uint32_t flags,
+                                                 int64_t hw, int lane) {
     using RS = ResetSlots<NS>;
-    const int64_t w0 = hw * kPoolWindow;
-    if (w0 >= n_envs) return;
-    // request bits of the window: lanes 0..7 the eight words of slot 0, lanes 8..15 those of slot 1
-    uint32_t w = 0;
-    if (lane < 16) w = pool.req_bits(lane >> 3)[(w0 >> 5) + (lane & 7)];
+    const PoolView<T> pool{base, (int64_t)epad, NS};
+    const PoolHeader<T> ACAS2D_AS4* hd = (const PoolHeader<T> ACAS2D_AS4*)base;
+    const int64_t n_envs = hd->n_envs, w0 = hw * kPoolWindow;
+    // a header written for another seed / shard / configuration (or never written): nothing useful to generate
+    if (hd->key != key || hd->n_traffic != (uint32_t)NS || w0 >= n_envs) return;
+    const uint32_t ACAS2D_AS4* bw = (const uint32_t ACAS2D_AS4*)pool.req_word(0, w0);
+    uint32_t w = 0;                                        // lane k < 16: word k of the window (slot k >> 3)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const uint32_t sw = bw[k]; w = lane == k ? sw : w; }
     unsigned long long m = __ballot(w != 0u);
+    if (m == 0) return;
+    const Params<T> p = load_const(&hd->p);
+    const ResetParamsT<T> rp = load_const(&hd->rp);
+    const uint32_t k0 = hd->k0, k1 = hd->k1;
+    const int64_t env_offset = hd->env_offset;
     const int slot = lane / RS::STRIDE;
-    while (m) {                                            // wave-uniform; almost always zero or one trip
+    while (m) {                                            // wave-uniform; almost always one trip
         int my_e = 0, my_s = 0;
+        uint32_t r = 0u;
         bool have = false;
         for (int k = 0; k < RS::SLOTS && m != 0; ++k) {    // reset slot k <- the next pending request
             const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
@@ -1131,17 +1174,17 @@ __device__ __forceinline__ void pool_helper_wave(const Params<T>& p, const Reset
             wl &= wl - 1u;
             if (lane == L) w = wl;
             if (wl == 0u) m &= m - 1ull;
-            if (slot == k) { my_e = (int)w0 + ((L & 7) << 5) + b; my_s = L >> 3; have = true; }
+            const int e_k = (int)w0 + ((L & 7) << 5) + b, s_k = L >> 3;
+            const uint32_t r_k = ((const uint32_t ACAS2D_AS4*)pool.req_ep(s_k))[e_k];     // scalar load
+            if (slot == k) { my_e = e_k; my_s = s_k; r = r_k; have = true; }
         }
-        uint32_t r = 0u;
-        if (have) r = pool.req_ep(my_s)[my_e];
         // a request names its slot by the parity of its episode; anything else is debris and is dropped
         const bool ok = have && r != 0u && (int)(r & 1u) == my_s && my_e < n_envs;
-        pool_generate<T, FAST, NS, R>(p, rp, pool, k0, k1, key, env_offset, ok, my_e, r, lane);
+        pool_generate<T, FAST, NS>(p, rp, pool, k0, k1, key, env_offset, ok, my_e, r, lane);
         if (have && lane % RS::STRIDE == 0) {
             pool.req_ep(my_s)[my_e] = 0u;
-            atomicAnd(&pool.req_bits(my_s)[my_e >> 5], ~(1u << (my_e & 31)));
-            if (ok) atomicAdd(pool.counters() + 2, 1u);
+            atomicAnd(pool.req_word(my_s, my_e), ~(1u << (my_e & 31)));
+            if (ok && (flags & 1u)) atomicAdd(pool.counters() + 2, 1u);
         }
     }
 }
@@ -1315,7 +1358,6 @@ __device__ __forceinline__ void flush_rows(const T* __restrict__ tile, T* __rest
 // at D = 8, no LDS, no vector loads.  Weights arrive TRANSPOSED ([in][out], row-major) so that one
 // input's 64 outgoing weights are contiguous.  float32 math in both builds (the reference's
 // policy.predict() runs its float32 torch module on float32-cast observations).
-#define ACAS2D_AS4 __attribute__((address_space(4)))
 struct PolicyW {
     const float *w1t, *b1, *w2t, *b2, *w3, *b3;      // [D][64], [64], [64][64], [64], [64], [1]
     void* actions_out;                               // T[n_steps][E]: the action each step took
@@ -1404,8 +1446,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     const PoolView<T> pool{pk.base, (int64_t)pk.epad, NS};
     if constexpr (POOL) {
         if (blockIdx.x < helpers) {                // this workgroup refills pool slots and steps nothing
-            pool_helper_wave<T, FAST, NS>(p_arg, rp, pool, k0, k1, pk.key, env_offset, n_envs,
-                                          (int64_t)blockIdx.x * kWavesPerBlock + wib, lane);
+            pool_helper_wave<T, FAST, NS>(pk.base, pk.epad, pk.key, pk.flags, (int64_t)blockIdx.x * kWavesPerBlock + wib, lane);
             return;
         }
     }
@@ -1622,10 +1663,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                             *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
                         }
                         dm &= ~fm;
-                        if (lane == 0) atomicAdd(pool.counters() + 0, (uint32_t)__popcll(fm));
+                        if ((pk.flags & 1u) && lane == 0) atomicAdd(pool.counters() + 0, (uint32_t)__popcll(fm));
                     }
                 }
-                if (dm != 0 && lane == 0) atomicAdd(pool.counters() + 1, (uint32_t)__popcll(dm));
+                if ((pk.flags & 1u) && dm != 0 && lane == 0) atomicAdd(pool.counters() + 1, (uint32_t)__popcll(dm));
             }
             if constexpr (POOL) {
                 // reward / done / outcome leave only now: issued before the commit they would stand between the
@@ -1716,7 +1757,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                         // env's next-but-one finish: ask the next launch's helper waves to put episode + 2 there
                         const int64_t e = e_wave + el;
                         pool.req_ep((int)(episode & 1u))[e] = episode + 2u;
-                        atomicOr(&pool.req_bits((int)(episode & 1u))[e >> 5], 1u << (e & 31));
+                        atomicOr(pool.req_word((int)(episode & 1u), e), 1u << (e & 31));
                     }
                 }
                 if (last || fresh) {
@@ -1807,11 +1848,22 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams 
             using RS = ResetSlots<NS>;
             const PoolView<T> pool{pk.base, (int64_t)pk.epad, NS};
             const uint32_t ep = selected ? s.episode[el] : 0u;
+            if (blockIdx.x == 0 && threadIdx.x == 0) {     // what the step kernels' helper waves generate with
+                PoolHeader<T>* hd = pool.header();
+                hd->key = pk.key; hd->k0 = k0; hd->k1 = k1; hd->n_traffic = (uint32_t)NS;
+                hd->env_offset = env_offset; hd->n_envs = n_envs;
+                hd->p = p;
+                hd->rp = ResetParamsT<T>{(T)rp.own_x0, (T)rp.own_y0, (T)rp.own_v, (T)rp.own_heading0, (T)rp.own_heading_jitter,
+                                         (T)rp.goal_x, (T)rp.goal_y, (T)rp.t0_x, (T)rp.t0_y_base, (T)rp.t0_y_span,
+                                         (T)rp.t0_heading_base, (T)rp.t0_heading_step, (T)rp.t0_heading_jitter,
+                                         (T)rp.tn_x_max, (T)rp.tn_y_max, (T)rp.speed_factor_min, (T)rp.speed_factor_max,
+                                         (T)rp.airspeed};
+            }
             if (selected && j == 0) {                      // pending refill requests of these envs are void now
                 const int64_t e = e_wave + el;
                 pool.req_ep(0)[e] = 0u; pool.req_ep(1)[e] = 0u;
-                atomicAnd(&pool.req_bits(0)[e >> 5], ~(1u << (e & 31)));
-                atomicAnd(&pool.req_bits(1)[e >> 5], ~(1u << (e & 31)));
+                atomicAnd(pool.req_word(0, e), ~(1u << (e & 31)));
+                atomicAnd(pool.req_word(1, e), ~(1u << (e & 31)));
             }
             unsigned long long sel = __ballot(selected && j == 0);
             const int slot = lane / RS::STRIDE;

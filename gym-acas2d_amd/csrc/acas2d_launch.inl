@@ -67,7 +67,7 @@ static uint32_t pool_key(const Acas2dConfig& c, uint64_t seed, int64_t env_offse
 template <typename T>
 static PoolArg make_pool(const Acas2dConfig& c, const Acas2dState& st, const Shape& sh, uint64_t seed,
                          int64_t env_offset, int64_t n_envs, int n_traffic) {
-    PoolArg pk{nullptr, 0u, 0u, 0, 0};
+    PoolArg pk{nullptr, 0u, 0u, 0, 0u};
     if (!st.pool || !pool_shape_ok(sh.C, sh.G, sh.packed)) return pk;
     pk.base = (unsigned char*)st.pool;
     pk.epad = (uint32_t)pool_epad(n_envs);
@@ -76,6 +76,7 @@ static PoolArg make_pool(const Acas2dConfig& c, const Acas2dState& st, const Sha
     // stepping workgroups keep their round-robin XCD placement
     const int64_t waves = pk.epad / kPoolWindow, blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
     pk.helper_blocks = (int32_t)((blocks + 7) / 8 * 8);
+    if (const char* st_ = getenv("ACAS2D_POOL_STATS")) pk.flags = st_[0] == '1' ? 1u : 0u;
     return pk;
 }
 

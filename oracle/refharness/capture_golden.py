@@ -14,6 +14,7 @@ GPU box; only the .npz/.json data written here does).  Recipe follows SURVEY.md 
 Outputs (all data, no code):
   tests/golden/ref_rollout_n{N}.npz   random-action rollouts with reset-on-done, N in {1,3,8,64}
   tests/golden/ref_edge_n{N}.npz      single steps from hand-placed states (thresholds, wrap, NaN)
+  tests/golden/ref_records_n{N}.npz   the per-step record lists of ACAS2DGame behind testing_main.py's CSV columns
   tests/golden/ref_baseline_replay.npz  harness replay of baseline_main.simulate() (initial states
                                       + outcomes; cross-checked against the reference's own CSV)
   tests/golden/csv_baseline_digest.npz  digest of the reference's committed CSV
@@ -327,10 +328,69 @@ def baseline_replay(digest):
     print("wrote", path)
 
 
+RECORD_LISTS = ("heading_record", "d_sep_record", "a_lat_record", "d_goal_record", "delta_h_goal_record",
+                "v_closing_record", "d_cpa_record", "d_dev_record", "step_reward_d_goal_record",
+                "step_reward_h_goal_record", "step_reward_d_cpa_record", "step_reward_d_dev_record",
+                "step_reward_record")
+
+
+def capture_records(n_traffic, episodes, seed_py, seed_actions, max_steps=1000):
+    """testing_main.simulate()'s harvest (testing_main.py:84-105) for `episodes` random-action episodes:
+    every per-step record list ACAS2DGame keeps (game.py:45-75, filled at :132-160, :231-241, :266-276)
+    plus d_path, path, traffic_paths -- what testing_main.py:114-138 writes to its CSV.  Ragged lists are
+    stored concatenated (episode e = rows off[e] .. off[e + 1])."""
+    set_n_traffic(n_traffic)
+    random.seed(seed_py)
+    rng = np.random.default_rng(seed_actions)
+    with quiet():
+        env = ACAS2DEnv()
+    own0, trf0, goal0, acts, off_a = [], [], [], [], [0]
+    recs = {k: [] for k in RECORD_LISTS}
+    paths, tpaths, off_r = [], [], [0]
+    outcome, steps, total, d_path = [], [], [], []
+    for _ in range(episodes):
+        with quiet():
+            env.reset()
+        g = env.game
+        own0.append(own_state(g)); trf0.append(traffic_state(g)); goal0.append([float(g.goal_x), float(g.goal_y)])
+        for _t in range(max_steps):
+            a = float(rng.uniform(-1.0, 1.0))
+            acts.append(a)
+            with quiet():
+                _o, _r, d, _i = env.step(np.array([a], dtype=np.float64))
+            if d:
+                break
+        g = env.game
+        n = len(g.heading_record)
+        for k in RECORD_LISTS:
+            assert len(getattr(g, k)) == n, (k, len(getattr(g, k)), n)
+            recs[k] += [float(v) for v in getattr(g, k)]
+        assert len(g.path) == n and all(len(tp) == n for tp in g.traffic_paths)
+        paths += [[float(x), float(y)] for x, y in g.path]
+        tpaths += [[[float(tp[i][0]), float(tp[i][1])] for tp in g.traffic_paths] for i in range(n)]
+        off_r.append(off_r[-1] + n)
+        off_a.append(len(acts))
+        outcome.append(0 if g.outcome is None else int(g.outcome)); steps.append(int(g.steps))
+        total.append(float(g.total_reward)); d_path.append(float(g.d_path))
+    path = os.path.join(OUT, "ref_records_n%d.npz" % n_traffic)
+    np.savez_compressed(path, n_traffic=np.int32(n_traffic), own0=np.array(own0), trf0=np.array(trf0),
+                        goal0=np.array(goal0), actions=np.array(acts), off_actions=np.array(off_a),
+                        off_records=np.array(off_r), path=np.array(paths), traffic_paths=np.array(tpaths),
+                        outcome=np.array(outcome), steps=np.array(steps), total_reward=np.array(total),
+                        d_path=np.array(d_path), **{k: np.array(v) for k, v in recs.items()})
+    print("wrote", path, "episodes", episodes, "rows", off_r[-1])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--records-only" in sys.argv:
+        capture_records(1, 6, seed_py=31, seed_actions=5)
+        capture_records(3, 6, seed_py=33, seed_actions=6)
+        sys.exit(0)
     digest = csv_digest()
     baseline_replay(digest)
     for n, steps in ((1, 2500), (3, 1500), (8, 1000), (64, 160)):
         capture_rollout(n, steps, seed_py=13 + n, seed_actions=n)
         capture_edges(n, seed=100 + n)
+    capture_records(1, 6, seed_py=31, seed_actions=5)
+    capture_records(3, 6, seed_py=33, seed_actions=6)

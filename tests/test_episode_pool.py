@@ -3,10 +3,14 @@ every env pre-generated in HBM, so that ACAS2DGame.__init__ + the first observe(
 (game.py:80-116, environment.py:44-48) are not computed at the end of the step launch.  The pool is a
 CACHE of the reset distribution: every result must be bit-identical with and without it, in every
 situation that can leave a slot stale, and in steady state (almost) every reset must be served from it."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+os.environ["ACAS2D_POOL_STATS"] = "1"        # event counters in the pool header (off by default: atomics)
 
 torch = pytest.importorskip("torch")
 
@@ -51,17 +55,21 @@ def test_pool_is_a_pure_cache(g, dtype_name, N, E, T):
     a, b = _pair(g, E, N, dtype)
     _same([a.reset().clone()], [b.reset().clone()], "reset")
     gen = torch.Generator(device="cuda:0").manual_seed(7)
-    finished = 0
+    finished, c_early, f_early = 0, None, 0
     for t in range(T):
         act = torch.rand(E, generator=gen, device="cuda:0", dtype=dtype) * 2 - 1
         sa, sb = _snapshot(a, a.step(act)), _snapshot(b, b.step(act))
         _same(sa, sb, "step %d" % t)
         finished += int(sa[2].sum())
+        if t == 4:
+            c_early, f_early = a.pool_counters(), finished
     c = a.pool_counters()
     assert finished > 20 and c["pool"] + c["in_step"] == finished, (finished, c)
-    # steady state: a reset is generated inside the step only when more envs of one wave may finish at once
-    # than the wave prefetches first observations for (kPoolRows = 4) -- rare with this workload
-    assert c["pool"] >= 0.97 * finished, (finished, c)
+    # A reset is generated inside the step only when more envs of one wave may finish at once than the wave
+    # prefetches first observations for (kPoolRows = 4): the burst right after reset() (a fifth of the fresh
+    # episodes start inside a collision disc and end at step 1, game.py:109-110) and hardly ever after it.
+    late, late_pool = finished - f_early, c["pool"] - c_early["pool"]
+    assert late > 20 and late_pool >= 0.99 * late, (finished, c_early, c)
     assert c["refilled"] >= c["pool"] + c["in_step"] - E      # every reset asked for one refill (the last step's are pending)
 
 

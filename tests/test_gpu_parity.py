@@ -454,8 +454,7 @@ def test_f32_reset_names_the_same_episodes(g, O):
     equal to the float64 oracle up to float32 rounding of the 1600-px / 360-degree ranges (positions
     2.5e-4, headings 6e-5); the float64 build is bit-equal to the oracle (test_f64_auto_reset_vs_oracle)."""
     E, N = 4096, 8
-    ref = O.OracleEnvs(E, N, seed=5, auto_reset=True)
-    ref.reset()
+    ref = None
 
     def close_to_oracle(env, sel):
         assert np.abs(env.trf_x[sel] - ref.trf_x[sel]).max() < 2.5e-4
@@ -466,6 +465,8 @@ def test_f32_reset_names_the_same_episodes(g, O):
         assert np.array_equal(env.trf_v[sel], ref.trf_v[sel])
 
     for pool in (True, False):
+        ref = O.OracleEnvs(E, N, seed=5, auto_reset=True)
+        ref.reset()
         env = GpuEngine(g, E, N, dtype=torch.float32, auto_reset=True, seed=5)
         if not pool:
             env.v = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, auto_reset=True, seed=5, episode_pool=False)
