@@ -96,6 +96,11 @@ using ResetParams = ResetParamsT<double>;
 template <typename T, bool ROLLOUT>
 using StepResetParams = ResetParamsT<typename std::conditional<ROLLOUT, double, T>::type>;
 
+// Per-step record row behind testing_main.py:114-138's CSV columns (the lists ACAS2DGame appends to at
+// game.py:132-160, :231-241, :266-276): psi, d_sep, a_lat, d_goal, delta_heading, v_closing, d_cpa, d_dev,
+// r_d_goal, r_h_goal, r_d_cpa, r_d_dev, r_step; three spare values.
+constexpr int kTraceWidth = 16;
+
 template <typename T>
 struct State {
     T *own_x, *own_y, *own_psi, *own_v, *goal_x, *goal_y;
@@ -104,6 +109,7 @@ struct State {
     T* total_reward;
     uint8_t* status;
     uint32_t* episode;
+    T* trace;                 // optional [E][kTraceWidth] (latching kernels and reset only), see write_trace()
 };
 
 template <typename T>
@@ -122,7 +128,8 @@ template <typename T>
 __device__ __forceinline__ State<T> rebase(const State<T>& s, int64_t e0, int N) {
     return State<T>{s.own_x + e0, s.own_y + e0, s.own_psi + e0, s.own_v + e0, s.goal_x + e0, s.goal_y + e0,
                     s.trf_x + e0 * N, s.trf_y + e0 * N, s.trf_psi + e0 * N, s.trf_v + e0 * N,
-                    s.steps + e0, s.total_reward + e0, s.status + e0, s.episode + e0};
+                    s.steps + e0, s.total_reward + e0, s.status + e0, s.episode + e0,
+                    s.trace ? s.trace + e0 * kTraceWidth : nullptr};
 }
 template <typename T>
 __device__ __forceinline__ StepIO<T> rebase(const StepIO<T>& io, int64_t e0, int D) {
@@ -299,6 +306,38 @@ __device__ __forceinline__ T step_reward_5(const Params<T>& p, T v_closing, T ps
     }
 }
 
+// The four sub-rewards the reference logs next to step_reward_5 (game.py:156-159, :272-275):
+// goal_distance_reward rewards.py:44-50, heading_reward :5-9, closest_approach_reward :12-16,
+// plan_deviation_reward :19-27 -- each in the formulation of the build (see step_reward_5 above).
+template <typename T, bool FAST>
+__device__ __forceinline__ void reward_parts(const Params<T>& p, T v_closing, T psi, T phi, T d_cpa, T d_goal,
+                                             T d_dev, T& r_d_goal, T& r_h_goal, T& r_d_cpa, T& r_d_dev) {
+    const T ad = m_abs(d_dev);
+    if constexpr (FAST) {
+        r_d_goal = py_min1(pow4(m_fma(-d_goal, p.inv_rw_d_goal_max, T(1))));
+        r_h_goal = pow4(m_fma(-delta_heading(psi, phi), T(1.0 / 180.0), T(1)));
+        r_d_cpa = (v_closing > T(0)) ? T(1) : py_min1(pow4(d_cpa * p.inv_safe_distance));
+        r_d_dev = (ad > p.rw_d_dev_max) ? T(0) : f_sqrt(m_fma(-ad, p.inv_rw_d_dev_max, T(1)));
+    } else {
+        r_d_goal = py_min1(pow4(T(1) - d_goal / p.rw_d_goal_max));
+        r_h_goal = pow4(T(1) - delta_heading(psi, phi) / T(180));
+        r_d_cpa = (v_closing > T(0)) ? T(1) : py_min1(pow4(d_cpa / p.safe_distance));
+        r_d_dev = (ad > p.rw_d_dev_max) ? T(0) : m_sqrt(T(1) - ad / p.rw_d_dev_max);
+    }
+}
+
+// One row of the record table: `r_step` is what the reference appends to step_reward_record -- the
+// undiscounted step_reward_5 at construction (game.py:160), r_step * tdf in evaluate() (:276).
+template <typename T, bool FAST>
+__device__ __forceinline__ void write_trace(const Params<T>& p, T* row, T psi, T d_sep, T a_lat, T h_goal, T d_goal,
+                                            T d_dev, T v_closing, T d_cpa, T r_step) {
+    T a, b, c, d;
+    reward_parts<T, FAST>(p, v_closing, psi, h_goal, d_cpa, d_goal, d_dev, a, b, c, d);
+    row[0] = psi; row[1] = d_sep; row[2] = a_lat; row[3] = d_goal; row[4] = delta_heading(psi, h_goal);
+    row[5] = v_closing; row[6] = d_cpa; row[7] = d_dev; row[8] = a; row[9] = b; row[10] = c; row[11] = d;
+    row[12] = r_step; row[13] = T(0); row[14] = T(0); row[15] = T(0);
+}
+
 // ---- cross-lane helpers within a group of G lanes ------------------------------------------------
 // Groups of 2 or 4 lanes sit inside a DPP quad: the exchange is one v_mov_b32 with a quad_perm
 // modifier (no LDS crossbar round trip as with ds_bpermute, which cost the headline (4,2) shape
@@ -359,8 +398,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 // XCD-aware block remap: blocks are dealt round-robin over the 8 XCDs, so give each XCD one
 // contiguous eighth of the env range (its L2 then sees whole cache lines and the same envs on
 // every step).  Speed only -- any placement is correct.
-__device__ __forceinline__ int64_t remap_block(uint32_t first = 0u) {
-    const uint32_t nb = gridDim.x - first, b = blockIdx.x - first;   // `first` leading workgroups have another role
+__device__ __forceinline__ int64_t remap_block(uint32_t trailing = 0u) {
+    const uint32_t nb = gridDim.x - trailing, b = blockIdx.x;        // `trailing` last workgroups have another role
     if ((nb & 7u) == 0u) return (int64_t)(b & 7u) * (nb >> 3) + (b >> 3);
     return b;
 }
@@ -625,6 +664,23 @@ __device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int i0)
     t.x = *reinterpret_cast<const V*>(s.trf_x + i0);
     t.y = *reinterpret_cast<const V*>(s.trf_y + i0);
     return t;
+}
+
+// game.py:162-166 minimum_separation() as action() logs it (game.py:236-237): the player has moved, the
+// traffic has not yet.  Record rows only (the latching kernels / reset when a trace buffer is given).
+template <typename T, int C, int G, bool PACKED>
+__device__ __forceinline__ T minimum_separation(const State<T>& s, const Own<T>& o, const Traffic<T, C>& tr, int e,
+                                                int j, int N) {
+    T m = T(1) / T(0);                                     // float("inf") for an env without traffic
+    if constexpr (PACKED) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) { const T d = distance(o.x, o.y, tr.x.v[k], tr.y.v[k]); m = d < m ? d : m; }
+    } else {
+        for (int n = j; n < N; n += G) { const T d = distance(o.x, o.y, s.trf_x[e * N + n], s.trf_y[e * N + n]); m = d < m ? d : m; }
+    }
+#pragma unroll
+    for (int w = 1; w < G; w <<= 1) { const T q = __shfl_xor(m, w, 64); m = q < m ? q : m; }
+    return m;
 }
 
 // game.py:194-220 observe() (+ the traffic half of action() when `move`): every lane computes the
@@ -1414,7 +1470,7 @@ __device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&
 // arithmetic is this same code, so rollout(T) == T x step() bit for bit.
 // With POLICY (rollout, one lane per env) the action of every step comes from policy_action() on the
 // previous observation instead of from actions[t][E], which becomes an output.
-// With POOL (per-step launch, packed shape, auto-reset) the first pk.helper_blocks workgroups refill the
+// With POOL (per-step launch, packed shape, auto-reset) the last pk.helper_blocks workgroups refill the
 // episode pool and the stepping waves take finished envs' next episodes from it (see "the episode pool").
 template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false,
           bool POOL = false>
@@ -1445,8 +1501,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     const uint32_t helpers = POOL ? (uint32_t)pk.helper_blocks : 0u;
     const PoolView<T> pool{pk.base, (int64_t)pk.epad, NS};
     if constexpr (POOL) {
-        if (blockIdx.x < helpers) {                // this workgroup refills pool slots and steps nothing
-            pool_helper_wave<T, FAST, NS>(pk.base, pk.epad, pk.key, pk.flags, (int64_t)blockIdx.x * kWavesPerBlock + wib, lane);
+        // The LAST workgroups of the grid refill pool slots and step nothing: dispatched behind the stepping
+        // workgroups, their waves are the youngest on their SIMDs and yield the issue slots to the stepping
+        // waves (arbitration is by age), and their short chain still ends well before the launch does.
+        if (blockIdx.x >= gridDim.x - helpers) {
+            pool_helper_wave<T, FAST, NS>(pk.base, pk.epad, pk.key, pk.flags,
+                                          (int64_t)(blockIdx.x - (gridDim.x - helpers)) * kWavesPerBlock + wib, lane);
             return;
         }
     }
@@ -1570,8 +1630,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // for its load there with s_waitcnt vmcnt(0) -- i.e. for every store issued since.
             asm volatile("" : "+v"(episode));
             // POOL: between the player side and the traffic side, fetch the next episodes of the envs that may finish
+            T d_sep = T(0);                               // record rows only
             auto pool_fetch = [&](const OwnCtx<T>& c) {
                 if constexpr (POOL) pf.fetch(p, pool, o, c, tr, steps, episode, e_wave, el, j, lane, active);
+                if constexpr (!AUTO_RESET) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); }
             };
             Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
                                                        ROLLOUT ? &trig : nullptr, pool_fetch);
@@ -1580,6 +1642,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
             if constexpr (FAST) rw = rw * m_fma(-(T)steps, p.inv_max_steps, T(1));
             else rw = rw * (T(1) - ((T)steps / (T)p.max_steps));              // :262-263
+            if constexpr (!AUTO_RESET) {                                      // :266-276, the record lists
+                if (s.trace && j == 0 && active)
+                    write_trace<T, FAST>(p, s.trace + el * kTraceWidth, o.psi, d_sep, o.a_lat, r.h_goal, r.d_goal, r.d_dev,
+                                         r.v_closing0, r.d_cpa0, rw);
+            }
             const bool at_goal = r.d_goal < p.goal_radius;                    // :191-192
             if (r.collided) rw += p.reward_collision;                         // :279-280
             if (at_goal) rw += p.reward_goal;                                 // :283-284
@@ -1801,7 +1868,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
 // ACAS2DEnv.reset(), environment.py:44-48 (do_init > 0: fresh episodes; == 0: keep the injected state;
 // < 0: leave the state alone), then -- POOL -- the pool slots of the selected envs for episode + 1, + 2.
 template <typename T, int C, int G, bool PACKED, bool FAST, bool POOL>
-__global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams rp, State<T> s_arg,
+__global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetParams rp, State<T> s_arg,
                                                        const uint8_t* __restrict__ mask, T* obs,
                                                        int do_init, uint32_t k0, uint32_t k1,
                                                        int64_t env_offset, int64_t n_envs, int N,
@@ -1812,6 +1879,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams 
     const int wib = wave_in_block();
     const int64_t e_wave = (remap_block() * kWavesPerBlock + wib) * EPW;
     if (e_wave >= n_envs) return;                          // whole wave idle
+    const Params<T> p = pinned(p_arg);
     const int D = 5 + 3 * N;
     const State<T> s = rebase(s_arg, e_wave, N);
     const bool selected = e_wave + el < n_envs && (!mask || mask[e_wave + el]);
@@ -1831,7 +1899,12 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p, ResetParams 
         }
         if (obs) {
             steps += 1;
-            observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row);
+            T d_sep = T(0);
+            auto sep = [&](const OwnCtx<T>&) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); };
+            const Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row, true, nullptr, sep);
+            if (s.trace && j == 0)                        // game.py:132-160: the records' first entries
+                write_trace<T, FAST>(p, s.trace + el * kTraceWidth, o.psi, d_sep, T(0), r.h_goal, r.d_goal, r.d_dev, r.v_closing0,
+                                     r.d_cpa0, step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev));
             wave_lds_fence();
             T* dst = obs + (e_wave + el) * D;             // masked rows are not contiguous: per-row copy
             for (int i = j; i < D; i += G) dst[i] = row[i];

@@ -39,7 +39,7 @@ template <typename T>
 static State<T> make_state(const Acas2dState& s) {
     return State<T>{(T*)s.own_x, (T*)s.own_y, (T*)s.own_psi, (T*)s.own_v, (T*)s.goal_x, (T*)s.goal_y,
                     (T*)s.trf_x, (T*)s.trf_y, (T*)s.trf_psi, (T*)s.trf_v, s.steps,
-                    (T*)s.total_reward, s.status, s.episode};
+                    (T*)s.total_reward, s.status, s.episode, (T*)s.trace};
 }
 
 // ---- the episode pool (Acas2dState.pool) -----------------------------------------------------------------
@@ -72,11 +72,11 @@ static PoolArg make_pool(const Acas2dConfig& c, const Acas2dState& st, const Sha
     pk.base = (unsigned char*)st.pool;
     pk.epad = (uint32_t)pool_epad(n_envs);
     pk.key = pool_key(c, seed, env_offset, n_traffic);
-    // one helper wave per kPoolWindow envs, in whole workgroups, a multiple of 8 of them so that the
-    // stepping workgroups keep their round-robin XCD placement
+    // one helper wave per kPoolWindow envs, in whole workgroups
     const int64_t waves = pk.epad / kPoolWindow, blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    pk.helper_blocks = (int32_t)((blocks + 7) / 8 * 8);
+    pk.helper_blocks = (int32_t)blocks;
     if (const char* st_ = getenv("ACAS2D_POOL_STATS")) pk.flags = st_[0] == '1' ? 1u : 0u;
+    if (const char* hb = getenv("ACAS2D_POOL_HELPER_BLOCKS")) pk.helper_blocks = atoi(hb);   // diagnostic: 0 = nobody refills
     return pk;
 }
 
@@ -120,7 +120,7 @@ static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, c
                        const ResetParamsT<T>& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
                        int64_t env_offset, int64_t n_envs, int N, const PoolArg& pk) {
     if constexpr (pool_shape_ok(C, G, PACKED)) {
-        if (auto_reset && pk.base) {          // the pooled variant: pk.helper_blocks refill workgroups lead the grid
+        if (auto_reset && pk.base) {          // the pooled variant: pk.helper_blocks refill workgroups close the grid
             hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false, false, true>),
                                dim3(g.grid + (unsigned)pk.helper_blocks), dim3(kBlock), g.lds_bytes, stream,
                                p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{}, pk);

@@ -114,6 +114,15 @@ typedef struct Acas2dState {
      * maintains the pool: call acas2d_reset_*(do_init = -1) after a rollout (or after writing episode[])
      * before the next acas2d_step_*.  Used by acas2d_step_* for packed work shapes with n_traffic <= 19. */
     void *pool;
+    /* Optional (NULL = off): T[E][16], the per-step record row behind testing_main.py:114-138's CSV columns
+     * (the lists ACAS2DGame appends to, game.py:132-160, :231-241, :266-276):
+     *   [0] psi  [1] d_sep (minimum separation AFTER the player moved and BEFORE the traffic did, :236-237)
+     *   [2] a_lat  [3] d_goal  [4] delta_heading  [5] v_closing  [6] d_cpa  [7] d_dev
+     *   [8] r_d_goal  [9] r_h_goal  [10] r_d_cpa  [11] r_d_dev  [12] r_step (step reward before the terminal
+     *   bonuses; the undiscounted step_reward_5 in the row acas2d_reset_* writes, :160)  [13..15] zero.
+     * Written by acas2d_step_* WITHOUT ACAS2D_AUTO_RESET (the single-env semantics those scripts run) and by
+     * acas2d_reset_* when it computes an observation. */
+    void *trace;
 } Acas2dState;
 
 /* Inputs / outputs of one step, device pointers.  term_obs, ep_return, ep_steps may be NULL. */
