@@ -47,9 +47,9 @@ def _pair(g, E, N, dtype, seed=21, config=None):
 
 
 @pytest.mark.parametrize("dtype_name,N,E,T", (("float32", 8, 4096 + 37, 400), ("float32", 3, 5000, 300),
-                                              ("float32", 1, 3000, 500), ("float32", 16, 1024, 120),
+                                              ("float32", 1, 3000, 900), ("float32", 16, 1024, 120),
                                               ("float32", 4, 2048, 200), ("float64", 8, 2048, 250),
-                                              ("float64", 3, 1500, 200), ("float64", 1, 999, 300)))
+                                              ("float64", 3, 1500, 200), ("float64", 1, 999, 900)))
 def test_pool_is_a_pure_cache(g, dtype_name, N, E, T):
     dtype = getattr(torch, dtype_name)
     a, b = _pair(g, E, N, dtype)
