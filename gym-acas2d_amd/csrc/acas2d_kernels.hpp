@@ -1961,8 +1961,10 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
 struct Shape { int C, G; bool packed; };
 Shape choose_shape(int n_traffic, int elem_size);
 // shapes whose step kernel has a pooled variant (must agree with step_kernel's static_assert)
-constexpr bool pool_shape_ok(int C, int G, bool packed) {
-    return packed && C * G + 1 <= 32 && 5 + 3 * C * G <= 64;
+// float32 only: the float64 parity build is bound by its libm transcendentals (25 us per launch at
+// 65 536 x 8), not by the reset tail, and its pooled variants ran out of SGPRs (200+ spilled to VGPR lanes).
+constexpr bool pool_shape_ok(int C, int G, bool packed, int elem_size) {
+    return elem_size == 4 && packed && C * G + 1 <= 32 && 5 + 3 * C * G <= 64;
 }
 
 template <typename T>

@@ -68,7 +68,7 @@ template <typename T>
 static PoolArg make_pool(const Acas2dConfig& c, const Acas2dState& st, const Shape& sh, uint64_t seed,
                          int64_t env_offset, int64_t n_envs, int n_traffic) {
     PoolArg pk{nullptr, 0u, 0u, 0, 0u};
-    if (!st.pool || !pool_shape_ok(sh.C, sh.G, sh.packed)) return pk;
+    if (!st.pool || !pool_shape_ok(sh.C, sh.G, sh.packed, (int)sizeof(T))) return pk;
     pk.base = (unsigned char*)st.pool;
     pk.epad = (uint32_t)pool_epad(n_envs);
     pk.key = pool_key(c, seed, env_offset, n_traffic);
@@ -119,7 +119,7 @@ template <typename T, int C, int G, bool PACKED>
 static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, const Params<T>& p,
                        const ResetParamsT<T>& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
                        int64_t env_offset, int64_t n_envs, int N, const PoolArg& pk) {
-    if constexpr (pool_shape_ok(C, G, PACKED)) {
+    if constexpr (pool_shape_ok(C, G, PACKED, (int)sizeof(T))) {
         if (auto_reset && pk.base) {          // the pooled variant: pk.helper_blocks refill workgroups close the grid
             hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false, false, true>),
                                dim3(g.grid + (unsigned)pk.helper_blocks), dim3(kBlock), g.lds_bytes, stream,
@@ -156,7 +156,7 @@ template <typename T, int C, int G, bool PACKED>
 static void reset_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
                         const State<T>& s, const uint8_t* mask, T* obs, int do_init, uint32_t k0, uint32_t k1,
                         int64_t env_offset, int64_t n_envs, int N, const PoolArg& pk) {
-    hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, kFast, pool_shape_ok(C, G, PACKED)>), dim3(g.grid), dim3(kBlock),
+    hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, kFast, pool_shape_ok(C, G, PACKED, (int)sizeof(T))>), dim3(g.grid), dim3(kBlock),
                        g.lds_bytes, stream, p, rp, s, mask, obs, do_init, k0, k1, env_offset, n_envs, N, g.tile_elems, pk);
 }
 
@@ -336,7 +336,7 @@ template <typename T>
 int64_t pool_bytes(int64_t n_envs, int32_t n_traffic) {
     Shape sh;
     if (n_envs <= 0 || n_traffic < 1 || resolve_shape<T>(n_traffic, &sh)) return 0;
-    if (!pool_shape_ok(sh.C, sh.G, sh.packed)) return 0;
+    if (!pool_shape_ok(sh.C, sh.G, sh.packed, (int)sizeof(T))) return 0;
     return pool_bytes_for<T>(n_envs, n_traffic);
 }
 

@@ -28,6 +28,12 @@ class GameView:
     (testing_main.py:66-105, baseline_main.py:36-58): outcome, steps, total_reward, quit,
     episode, player, traffic, goal_x/goal_y, path, traffic_paths."""
 
+    # attribute name of each record list (game.py:57-75) <- column of ACAS2DVecEnv.trace
+    RECORD_LISTS = (("heading_record", 0), ("d_sep_record", 1), ("a_lat_record", 2), ("d_goal_record", 3),
+                    ("delta_h_goal_record", 4), ("v_closing_record", 5), ("d_cpa_record", 6), ("d_dev_record", 7),
+                    ("step_reward_d_goal_record", 8), ("step_reward_h_goal_record", 9),
+                    ("step_reward_d_cpa_record", 10), ("step_reward_d_dev_record", 11), ("step_reward_record", 12))
+
     def __init__(self, env):
         self._env = env
         self.episode = None
@@ -35,6 +41,13 @@ class GameView:
         self.manual = False
         self.path = []               # game.py:47,132,231
         self.traffic_paths = []      # game.py:49-50,134-135,232-233 (logged BEFORE traffic moves)
+        self.d_path = 0.0            # game.py:45,239: distance covered by the player
+        for name, _ in self.RECORD_LISTS:        # game.py:57-75, read by testing_main.py:91-103
+            setattr(self, name, [])
+
+    def _append_records(self, row):
+        for name, k in self.RECORD_LISTS:
+            getattr(self, name).append(float(row[k]))
 
     def _scalar(self, t):
         return t[0].item()
@@ -86,7 +99,7 @@ class ACAS2DEnv:
     def __init__(self, n_traffic=1, device="cuda", config=None, record_paths=True):
         self.config = config if config is not None else ACAS2DConfig(n_traffic=n_traffic)
         self._vec = ACAS2DVecEnv(1, device=device, dtype=torch.float64, auto_reset=False,
-                                 config=self.config)
+                                 config=self.config, record_trace=record_paths)
         self.record_paths = record_paths
         lo, hi = self.config.obs_low_high()
         self.observation_space = Box(low=np.array(lo, np.float64), high=np.array(hi, np.float64),
@@ -95,8 +108,15 @@ class ACAS2DEnv:
         self.game = GameView(self)
         self._new_game()             # the reference constructs a game in __init__ (environment.py:12)
 
-    def _new_game(self):
-        own, trf, goal = draw_episode(self.config, random)
+    def reset_to(self, own, trf, goal=None):
+        """reset() onto a GIVEN initial state instead of a drawn one (own = (x, y, psi, v), trf [N, 4], goal
+        (x, y)): replaying recorded episodes / fixtures.  Returns the first observation."""
+        own, trf = np.asarray(own, np.float64), np.asarray(trf, np.float64).reshape(self.config.n_traffic, 4)
+        goal = np.asarray(self.config.goal if goal is None else goal, np.float64)
+        return self._new_game((own, trf, goal))[0].cpu().numpy().astype(np.float64)
+
+    def _new_game(self, state=None):
+        own, trf, goal = draw_episode(self.config, random) if state is None else state
         obs = self._vec.set_state(own[None], trf[None], goal[None], steps=np.zeros(1, np.int32))
         episode = self.game.episode
         self.game = GameView(self)
@@ -105,7 +125,9 @@ class ACAS2DEnv:
             # plain Python floats: the reference's CSVs are read back with ast.literal_eval
             self.game.path.append((float(own[0]), float(own[1])))
             self.game.traffic_paths = [[(float(t[0]), float(t[1]))] for t in trf]
+            self.game._append_records(self._vec.trace[0].cpu().numpy())          # game.py:132-160
         self._last_trf = trf[:, :2].copy()
+        self._last_own = (float(own[0]), float(own[1]))
         return obs
 
     def reset(self):
@@ -122,14 +144,20 @@ class ACAS2DEnv:
         # ONE device -> host transfer per step: obs, reward, done and (for the records) the positions
         parts = [obs[0], reward[:1], done[:1].to(obs.dtype)]
         if self.record_paths:
-            parts += [v.own_x[:1], v.own_y[:1], v.trf_x[0], v.trf_y[0]]
+            parts += [v.own_x[:1], v.own_y[:1], v.trf_x[0], v.trf_y[0], v.trace[0]]
         host = torch.cat(parts).cpu().numpy()
         D, N = self.config.obs_dim, self.config.n_traffic
         if self.record_paths:
-            self.game.path.append((float(host[D + 2]), float(host[D + 3])))
+            x, y = float(host[D + 2]), float(host[D + 3])
+            self.game.path.append((x, y))
             for n, lst in enumerate(self.game.traffic_paths):       # logged BEFORE the traffic moved
                 lst.append((float(self._last_trf[n, 0]), float(self._last_trf[n, 1])))
             self._last_trf = np.stack([host[D + 4:D + 4 + N], host[D + 4 + N:D + 4 + 2 * N]], axis=1)
+            self.game._append_records(host[D + 4 + 2 * N:])         # game.py:234-238, :266-276
+            # game.py:239 d_path += distance(old, new) = sqrt(dot(d, d)) (kinematics.py:7-13)
+            dx, dy = self._last_own[0] - x, self._last_own[1] - y
+            self.game.d_path += float(np.sqrt(np.dot([dx, dy], [dx, dy])))
+            self._last_own = (x, y)
         return host[:D].astype(np.float64), float(host[D]), bool(host[D + 1] != 0), {}
 
     def render(self, mode="human"):

@@ -24,6 +24,9 @@ from .spaces import Box
 
 _STATE_FIELDS = ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y",
                  "trf_x", "trf_y", "trf_psi", "trf_v")
+# columns of ACAS2DVecEnv.trace (testing_main.py:123-137's names; game.py:132-160, :231-241, :266-276)
+TRACE_COLUMNS = ("psi", "d_sep", "a_lat", "d_goal", "delta_heading", "v_closing", "d_cpa", "d_dev",
+                 "r_d_goal", "r_h_goal", "r_d_cpa", "r_d_dev", "r_step")
 
 
 class LazyInfos(Sequence):
@@ -87,6 +90,9 @@ class ACAS2DVecEnv:
                    episode counter) only, never on how the envs are sharded
     auto_reset     VecEnv semantics (True) or the single-env "latch the outcome, freeze the
                    traffic" semantics of the reference (False; game.py:243-245)
+    record_trace   (auto_reset=False only) keep `trace` [E, 16]: the per-step record row behind
+                   testing_main.py:114-138's CSV columns (include/acas2d.h, Acas2dState.trace;
+                   TRACE_COLUMNS below), rewritten by every reset*() / set_state(observe=True) / step()
     episode_pool   keep the next two episodes of every env pre-generated in HBM (include/acas2d.h,
                    Acas2dState.pool) so that re-initialising a finished env does not sit at the end of
                    the step launch; a cache -- results are bit-identical with and without it
@@ -95,7 +101,8 @@ class ACAS2DVecEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, num_envs, n_traffic=1, device="cuda", dtype=torch.float32, seed=13,
-                 env_offset=0, auto_reset=True, keep_terminal_obs=True, config=None, episode_pool=True):
+                 env_offset=0, auto_reset=True, keep_terminal_obs=True, config=None, episode_pool=True,
+                 record_trace=False):
         if config is None:
             config = ACAS2DConfig(n_traffic=n_traffic)
         self.config = config
@@ -129,6 +136,9 @@ class ACAS2DVecEnv:
         self.episode = z(E, dt=torch.int32)            # bit pattern of the u32 counter
         nbytes = native.pool_bytes(E, N, 4 if dtype == torch.float32 else 8) if (episode_pool and auto_reset) else 0
         self.pool = torch.zeros(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+        if record_trace and auto_reset:
+            raise ValueError("record_trace needs auto_reset=False (the reference's single-env semantics)")
+        self.trace = z(E, len(TRACE_COLUMNS) + 3) if record_trace else None
         self._actions = z(E)
         self._obs = z(E, D)
         self._reward = z(E)

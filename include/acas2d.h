@@ -112,7 +112,9 @@ typedef struct Acas2dState {
      * another seed) is ignored -- the env is then re-initialised inside the step as without a pool.
      * acas2d_reset_* prepares the slots of the envs it resets; acas2d_rollout_* neither reads nor
      * maintains the pool: call acas2d_reset_*(do_init = -1) after a rollout (or after writing episode[])
-     * before the next acas2d_step_*.  Used by acas2d_step_* for packed work shapes with n_traffic <= 19. */
+     * before the next acas2d_step_*.  Used by acas2d_step_f32 for packed work shapes with n_traffic <= 19
+     * (acas2d_pool_bytes() is 0 for everything else, float64 included: that build is bound by its
+     * transcendentals, not by the reset tail). */
     void *pool;
     /* Optional (NULL = off): T[E][16], the per-step record row behind testing_main.py:114-138's CSV columns
      * (the lists ACAS2DGame appends to, game.py:132-160, :231-241, :266-276):

@@ -205,6 +205,50 @@ def test_records_in_the_reference_csv_layout(g, tmp_path):
     assert len(ast.literal_eval(rows[0]["Path"])) == 390 and len(ast.literal_eval(rows[0]["Traffic Paths"])[0]) == 390
 
 
+@pytest.mark.parametrize("N", (1, 3))
+def test_testing_main_record_columns_vs_reference(g, N, tmp_path):
+    """every column testing_main.py:114-138 writes -- Path Length and the thirteen per-step
+    record lists ACAS2DGame keeps (game.py:132-160, :231-241, :266-276) -- from the engine's trace rows
+    (include/acas2d.h, Acas2dState.trace), against the lists captured from the unmodified reference
+    (tests/golden/ref_records_n{N}.npz, oracle/refharness/capture_golden.py capture_records): random-action
+    episodes replayed from the captured initial states.  d_sep is the separation AFTER the player moved and
+    BEFORE the traffic did (:236-237 vs :243-245), r_step the step reward before the terminal bonuses."""
+    fx = H.load("ref_records_n%d.npz" % N)
+    env = g.ACAS2DEnv(n_traffic=N)
+    n_ep = len(fx["outcome"])
+    acts = iter(fx["actions"])
+    states = [(fx["own0"][i], fx["trf0"][i], fx["goal0"][i]) for i in range(n_ep)]
+    cols = g.records.simulate(env, episodes=n_ep, policy=lambda obs: np.array([next(acts)]), columns="testing",
+                              initial_states=states)
+    assert tuple(cols) == g.records.TESTING_COLUMNS
+    off = fx["off_records"]
+    worst = {}
+    for i in range(n_ep):
+        lo, hi = off[i], off[i + 1]
+        assert cols["Outcome"][i] == {1: "Goal", 2: "Collision", 3: "Timeout"}[int(fx["outcome"][i])]
+        assert cols["Time Steps"][i] == fx["steps"][i]
+        assert abs(cols["Total Reward"][i] - fx["total_reward"][i]) < 1e-8
+        assert abs(cols["Path Length"][i] - fx["d_path"][i]) < 1e-9
+        np.testing.assert_allclose(np.array(cols["Path"][i]), fx["path"][lo:hi], atol=1e-9, rtol=0)
+        np.testing.assert_allclose(np.array(cols["Traffic Paths"][i]).transpose(1, 0, 2), fx["traffic_paths"][lo:hi],
+                                   atol=1e-9, rtol=0)
+        for col, attr in g.records.TESTING_RECORDS:
+            got, want = np.array(cols[col][i]), fx[attr][lo:hi]
+            assert got.shape == want.shape, (col, got.shape, want.shape)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), col
+            err = float(np.nanmax(np.abs(got - want)))
+            worst[col] = max(worst.get(col, 0.0), err)
+            assert err < 1e-9, (i, col, err)
+    assert next(acts, None) is None                              # every recorded action was consumed
+    assert worst["a_lat"] == 0.0 and worst["psi"] < 1e-11
+    out = tmp_path / "testing.csv"
+    g.records.to_csv(cols, out)
+    import csv
+    csv.field_size_limit(1 << 30)
+    rows = list(csv.DictReader(open(out)))
+    assert list(rows[0]) == list(g.records.TESTING_COLUMNS) and len(rows) == n_ep
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N", (1, 3, 8, 64))
 def test_f32_single_step_vs_f64_oracle(g, O, N):
