@@ -74,10 +74,10 @@ def parse(argv=None):
     ap.add_argument("--no-collisions", action="store_true",
                     help="diagnostic (SURVEY.md 8d, C4): collision distance 0, so episodes end at the goal / by "
                          "timeout only and resets are rare -- isolates the step itself at large N_TRAFFIC")
-    ap.add_argument("--no-pool", action="store_true",
-                    help="A/B: without the episode pool (finished envs are re-initialised inside the step launch)")
-    ap.add_argument("--pool-stats", action="store_true",
-                    help="diagnostic: count pool hits / in-step resets / refills (atomics on the reset paths)")
+    ap.add_argument("--no-spec", action="store_true",
+                    help="A/B: without the speculative reset (every finished env is re-initialised at the end of its step)")
+    ap.add_argument("--reset-stats", action="store_true",
+                    help="diagnostic: count speculated / in-step resets (atomics on the reset paths)")
     ap.add_argument("--no-terminations", action="store_true",
                     help="diagnostic: no collisions, no goal, no timeout -- nothing ever finishes (the reset-free floor)")
     return ap.parse_args(argv)
@@ -237,7 +237,8 @@ class StepRunner:
 
 def make_env(g, E, N, dtype, dev, rank, args):
     env = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13, env_offset=rank * E,
-                         auto_reset=not args.no_auto_reset, episode_pool=not args.no_pool)
+                         auto_reset=not args.no_auto_reset, speculative_reset=not args.no_spec,
+                         count_resets=args.reset_stats)
     if args.no_collisions or args.no_terminations:
         env._ccfg.collision_dist = 0.0
     if args.no_terminations:
@@ -289,8 +290,6 @@ class RehearsalEnv:
 
 def main():
     args = parse()
-    if args.pool_stats:
-        os.environ["ACAS2D_POOL_STATS"] = "1"
     world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if world_env == 0 and args.gpus > 1:
         sys.exit(self_launch(args.gpus))
@@ -425,7 +424,7 @@ def main():
                              "grid_blocks": geo["grid_blocks"],
                              "parallelism": "env-index shards x%d, no collective on the step path" % world,
                              "episodes_finished": int(episodes),
-                             "episode_pool": env.pool_counters()}
+                             "speculative_reset": not args.no_spec, "reset_stats": env.reset_stats()}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(E, N, args.dtype),
                                "kernel": "acas2d::step_kernel<%s, C=%d, G=%d>" % ("float" if s == 4 else "double",

@@ -32,8 +32,6 @@ Shape choose_shape(int n, int elem_size) {
 
 template <typename T>
 int shape_geometry(int64_t n_envs, int32_t n_traffic, int32_t* lanes, int32_t* per_lane, int64_t* grid);
-template <typename T>
-int64_t pool_bytes(int64_t n_envs, int32_t n_traffic);
 
 }  // namespace acas2d
 
@@ -44,11 +42,6 @@ extern "C" {
 int acas2d_abi_version(void) { return ACAS2D_ABI_VERSION; }
 size_t acas2d_config_size(void) { return sizeof(Acas2dConfig); }
 size_t acas2d_state_size(void) { return sizeof(Acas2dState); }
-size_t acas2d_pool_bytes(int64_t n_envs, int32_t n_traffic, int32_t elem_size) {
-    if (elem_size == 4) return (size_t)pool_bytes<float>(n_envs, n_traffic);
-    if (elem_size == 8) return (size_t)pool_bytes<double>(n_envs, n_traffic);
-    return 0;
-}
 const char* acas2d_last_error(void) { return g_error; }
 
 int acas2d_step_f32(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dStepIO* io, uint32_t flags,

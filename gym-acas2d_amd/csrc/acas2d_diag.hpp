@@ -6,9 +6,8 @@
 #pragma once
 
 #ifdef ACAS2D_STAMPS
-namespace acas2d {
+// (included inside namespace acas2d)
 static __device__ unsigned long long* g_stamps = nullptr;   // [n_waves][16], set by acas2d_debug_set_stamps_*
-}
 #define ACAS2D_STAMP(k, wave_id, lane_id, drain)                                              \
     do {                                                                                      \
         if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \

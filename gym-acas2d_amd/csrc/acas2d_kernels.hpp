@@ -110,6 +110,8 @@ struct State {
     uint8_t* status;
     uint32_t* episode;
     T* trace;                 // optional [E][kTraceWidth] (latching kernels and reset only), see write_trace()
+    uint8_t* hint;            // optional [E]: may this env finish at the next step (see "speculative reset")
+    uint32_t* stats;          // optional [4]: diagnostic event counters (tests), see Acas2dState.stats
 };
 
 template <typename T>
@@ -129,7 +131,7 @@ __device__ __forceinline__ State<T> rebase(const State<T>& s, int64_t e0, int N)
     return State<T>{s.own_x + e0, s.own_y + e0, s.own_psi + e0, s.own_v + e0, s.goal_x + e0, s.goal_y + e0,
                     s.trf_x + e0 * N, s.trf_y + e0 * N, s.trf_psi + e0 * N, s.trf_v + e0 * N,
                     s.steps + e0, s.total_reward + e0, s.status + e0, s.episode + e0,
-                    s.trace ? s.trace + e0 * kTraceWidth : nullptr};
+                    s.trace ? s.trace + e0 * kTraceWidth : nullptr, s.hint ? s.hint + e0 : nullptr, s.stats};
 }
 template <typename T>
 __device__ __forceinline__ StepIO<T> rebase(const StepIO<T>& io, int64_t e0, int D) {
@@ -406,9 +408,12 @@ __device__ __forceinline__ int64_t remap_block(uint32_t trailing = 0u) {
 
 // ---- Philox4x32-10 counter-based reset RNG ---------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
+#ifndef ACAS2D_PHILOX_ROUNDS
+#define ACAS2D_PHILOX_ROUNDS 10          // diagnostic builds only: the reset chain's latency knob
+#endif
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ACAS2D_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;   // v_mad_u64_u32
         c = U4{(uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0};
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -468,7 +473,21 @@ template <typename T>
 struct Seen {
     T d_goal, h_goal, d_dev, v_closing0, d_cpa0;
     int collided;
+    int near;                 // HINT only: some traffic aircraft can be within the collision distance after the NEXT step
 };
+
+// ---- "may this env finish at the next step" (Acas2dState.hint) ---------------------------------------
+// Conservative by construction: in one step the player moves by exactly v dt and an aircraft by v_k dt
+// (aircraft.py:24-25), so the distance between them shrinks by at most (v + v_k) dt and the distance to the
+// goal by at most v dt; the slack (1e-4 relative on the motion, 0.01 px absolute) covers every rounding on the
+// way in both element types.  NaN compares false here exactly as in game.py:185-192.
+template <typename T> __device__ __forceinline__ T hint_dt(const Params<T>& p) { return p.dt * T(1.0001); }
+template <typename T> __device__ __forceinline__ T hint_collision_base(const Params<T>& p, T own_v) {
+    return m_fma(own_v, hint_dt(p), p.collision_dist + T(0.01));
+}
+template <typename T> __device__ __forceinline__ bool may_reach_goal(const Params<T>& p, T own_v, T d_goal) {
+    return d_goal < m_fma(own_v, hint_dt(p), p.goal_radius + T(0.01));
+}
 
 // ZERO_ACTION (a freshly reset episode: a_lat = 0, heading in [0, 360)): the one-step-ahead heading
 // of closing_speed() is the heading itself, bit for bit, so its sin / cos are not computed twice.
@@ -689,9 +708,9 @@ __device__ __forceinline__ T minimum_separation(const State<T>& s, const Own<T>&
 // Packed shapes get their traffic in registers (`tr`, loaded by the caller up front so that all
 // of a wave's loads are in flight together) and write the moved block back; the generic walk
 // loads / stores aircraft by aircraft.
-// `after_own(c)` runs between the player side and the traffic side (the step kernel's pool fetch).
+// `after_own(c)` runs between the player side and the traffic side (the record rows' minimum separation).
 struct NoHook { template <typename X> __device__ __forceinline__ void operator()(const X&) const {} };
-template <typename T, int C, int G, bool PACKED, bool FAST, typename Hook = NoHook>
+template <typename T, int C, int G, bool PACKED, bool FAST, bool HINT = false, typename Hook = NoHook>
 __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
                                            int e, int j, int N, int32_t steps, bool move,
                                            Traffic<T, C>& tr, T* __restrict__ row, bool store_traffic = true,
@@ -705,6 +724,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
     r.d_goal = c.d_goal; r.h_goal = c.h_goal; r.d_dev = c.d_dev;
     int coll = 0;
     T vc0 = T(0), dc0 = T(0);
+    const T near_base = HINT ? hint_collision_base(p, c.v) : T(0), near_dt = HINT ? hint_dt(p) : T(0);
     if constexpr (PACKED) {
         using V = Vec<T, C>;
         const int i0 = e * N + j * C;
@@ -770,6 +790,10 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
                 traffic_observe2(p, c, F2{tr.x.v[k], tr.x.v[k + 1]}, F2{tr.y.v[k], tr.y.v[k + 1]},
                                  F2{tr.v.v[k], tr.v.v[k + 1]}, F2{st[k], st[k + 1]}, F2{ct[k], ct[k + 1]}, d, dca, vc);
                 coll |= ((d.x < p.collision_dist) | (d.y < p.collision_dist)) ? 1 : 0;   // game.py:185-189
+                if constexpr (HINT) {
+                    const F2 thr = m_fma(F2{tr.v.v[k], tr.v.v[k + 1]}, F2{near_dt, near_dt}, F2{near_base, near_base});
+                    coll |= ((d.x < thr.x) | (d.y < thr.y)) ? 2 : 0;
+                }
                 const F2 dn = d * p.inv_d_sep_max, cn = dca * p.inv_d_cpa_max, vn = vc * p.inv_v_closing_max;
                 T* q = row + 5 + 3 * (j * C + k);                                 // game.py:205-210
                 q[0] = dn.x; q[1] = cn.x; q[2] = vn.x; q[3] = dn.y; q[4] = cn.y; q[5] = vn.y;
@@ -781,6 +805,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
                 T d, dca, vc;
                 traffic_observe<T, FAST>(p, c, tr.x.v[k], tr.y.v[k], tr.v.v[k], st[k], ct[k], d, dca, vc);
                 coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
+                if constexpr (HINT) coll |= (d < m_fma(tr.v.v[k], near_dt, near_base)) ? 2 : 0;
                 put_traffic_obs<T, FAST>(p, row + 5 + 3 * (j * C + k), d, dca, vc);
                 if (k == 0) { vc0 = vc; dc0 = dca; }
             }
@@ -798,11 +823,14 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
                 if (tpsi != psi_in) s.trf_psi[i] = tpsi;
             }
             coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
+            if constexpr (HINT) coll |= (d < m_fma(tv, near_dt, near_base)) ? 2 : 0;
             put_traffic_obs<T, FAST>(p, row + 5 + 3 * n, d, dca, vc);
             if (n == 0) { vc0 = vc; dc0 = dca; }
         }
     }
-    r.collided = group_or<G>(coll);
+    coll = group_or<G>(coll);
+    r.collided = coll & 1;
+    r.near = coll & 2;
     r.v_closing0 = group_bcast0<G>(vc0);                  // evaluate() reads traffic[0] only,
     r.d_cpa0 = group_bcast0<G>(dc0);                      // game.py:254-255
     if (j == 0) put_own_obs<T, FAST>(p, row, steps, o.psi, c);
@@ -813,7 +841,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
 // counter = (env_lo, env_hi, episode, entity) with entity 0 = the player (only its heading is random,
 // returned in opsi; game.py:85-92), entity n + 1 = traffic n (game.py:96-116); words: x (bit 31 of it =
 // starts_down for traffic 0), y, heading, airspeed factor.  The ONE formulation of the distribution per
-// element type: reset(), the in-step auto-reset and the episode pool all call it, so (seed, global env
+// element type: reset(), the in-step auto-reset and the speculative generation all call it, so (seed, global env
 // index, episode counter) names the same episode bit for bit whichever path draws it.  float64 draws use
 // 32 random bits per uniform; the float32 build draws in float32 from 24 bits (equal to the float64
 // evaluation rounded to float32 up to 1-2 ulp, at a fraction of its latency).
@@ -998,6 +1026,15 @@ template <int NS> struct ResetSlots {
     static constexpr int STRIDE = ENT <= 2 ? 2 : ENT <= 4 ? 4 : ENT <= 8 ? 8 : ENT <= 16 ? 16 : ENT <= 32 ? 32 : 64;
     static constexpr int SLOTS = 64 / STRIDE;
 };
+// One reset slot in the wave's LDS, in values of T: the new traffic block x[N] y[N] psi[N] v[N] (each 16-byte
+// aligned for the packed shapes' vector reads), the player's heading, the new episode's hint, and -- written
+// by the speculative generation only -- the new episode's first observation.  Slots start 16-byte aligned.
+template <typename T, int NS> struct SlotLayout {
+    static constexpr int W = 16 / (int)sizeof(T);
+    static constexpr int OWN_PSI = 4 * NS, HINT = 4 * NS + 1;
+    static constexpr int OBS = (4 * NS + 2 + W - 1) / W * W;
+    static constexpr int STRIDE = (OBS + 5 + 3 * NS + W - 1) / W * W;
+};
 
 // Resets the envs named by the lowest min(SLOTS, popcount(dm)) bits of `dm` (bit = lane of the env's
 // group leader, i.e. el * G); returns the mask of those bits.  Owner lanes find their slot as the rank of
@@ -1009,7 +1046,7 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
                                                                uint32_t episode_lane, T* __restrict__ tile,
                                                                T* __restrict__ scratch) {
     using RS = ResetSlots<NS>;
-    constexpr int N = NS, D = 5 + 3 * NS, SCR = 4 * NS + 1;
+    constexpr int N = NS, D = 5 + 3 * NS, SCR = SlotLayout<T, NS>::STRIDE;
     const int slot = lane / RS::STRIDE, ent = lane % RS::STRIDE;
     // slot k <- the k-th set bit of dm
     unsigned long long taken = 0;
@@ -1067,6 +1104,10 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
         psi_own = have ? scr[4 * N] : T(0);
     }
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+#ifdef ACAS2D_EXP_SKIP_FIRST_OBS
+    if (mine) { if (ent >= 1) { row[5 + 3 * (ent - 1)] = tx; row[6 + 3 * (ent - 1)] = ty; row[7 + 3 * (ent - 1)] = tv; } else { row[0] = psi_own; } }
+    return taken;
+#endif
     const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
     // environment.py:44-48: the new episodes' first observations (steps becomes 1)
     if (mine) {
@@ -1081,243 +1122,82 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
     return taken;
 }
 
-// ---- the episode pool (include/acas2d.h, Acas2dState.pool) ------------------------------------------
-// Re-initialising a finished env is ACAS2DGame.__init__ (game.py:80-116: one Philox block per aircraft)
-// plus the new episode's first observe(): ~1.2 us of dependent latency at the very END of the launch,
-// on the wave every other wave then waits for (the launch ends with its slowest wave; measured:
-// 5.8 us per launch with resets against 4.6 us when nothing ever finishes, 65 536 x 8).  The pool takes
-// that chain off the step.  Slot r & 1 of env e holds episode r -- traffic block, player heading, first
-// observation -- tagged with (r, key), for r = episode[e] + 1 and + 2.
-//   * a stepping wave tests, right after its loads, which of its envs CAN finish in this step
-//     (conservative: may_finish()) and fetches their next episode from the pool in the shadow of the
-//     arithmetic; a finished env whose fetched tag matches is re-initialised by register selects and one
-//     LDS row rewrite (pool commit), anything else falls back to the in-kernel generator below;
-//   * every reset posts ONE request: refill the slot just used (or skipped) with episode + 2.  That slot
-//     is not read again before the env's next-but-one finish, i.e. not in the next launch;
-//   * the first workgroups of the NEXT step launch are helper waves (pool_helper_wave): they scan the
-//     request bits, generate the requested episodes with the same per-entity functions as the in-kernel
-//     reset (same bits), store them and drop the requests -- off every stepping wave's path.
-// The pool is a cache: a stale or missing slot only costs the slow path.
-struct PoolArg {
-    unsigned char* base;      // nullptr = no pool
-    uint32_t epad;            // n_envs rounded up to a multiple of kPoolWindow
-    uint32_t key;             // hash of (seed, env_offset, reset distribution): slots of another key are stale
-    int32_t helper_blocks;    // leading workgroups of a step launch that refill slots
-    uint32_t flags;           // bit 0: count events in the header (diagnostics / tests)
-};
-constexpr int kPoolWindow = 256;     // envs scanned by one helper wave
-constexpr int kPoolHeader = 512;     // bytes
-
-// The pool's first bytes.  Written by reset_kernel (which has every launch constant) and read by the helper
-// waves of the step kernels with scalar loads INSIDE their own branch: a helper wave needs the launch
-// constants, the reset distribution and the RNG key, and as ordinary kernel arguments those were hoisted into
-// the entry block of the stepping waves too -- 46 SGPR spills and two more scalar-load round trips in front
-// of every wave's first global load (measured: +1.0 us per launch at 65 536 x 8).
-template <typename T>
-struct PoolHeader {
-    uint32_t counters[4];     // [0] resets served from the pool, [1] resets generated inside a step although a
-                              // pool is attached, [2] slots refilled by helper waves (only with PoolArg.flags & 1)
-    uint32_t key, k0, k1, n_traffic;
-    int64_t env_offset, n_envs;
-    Params<T> p;
-    ResetParamsT<T> rp;
-};
-static_assert(sizeof(PoolHeader<double>) <= kPoolHeader && sizeof(PoolHeader<float>) <= kPoolHeader, "pool header");
-
-template <typename T>
-struct PoolView {
-    unsigned char* base;
-    int64_t epad;
-    int N;
-    // byte offsets; every block is a multiple of 16 bytes because epad is a multiple of 256
-    __host__ __device__ int64_t off_req_ep() const { return kPoolHeader + (epad >> 2); }            // after 2 x epad/8
-    __host__ __device__ int64_t off_tag() const { return off_req_ep() + 8 * epad; }                 // after 2 x epad x 4
-    __host__ __device__ int64_t off_own_psi() const { return off_tag() + 16 * epad; }               // after 2 x epad x 8
-    __host__ __device__ int64_t off_trf() const { return off_own_psi() + 2 * epad * (int64_t)sizeof(T); }
-    __host__ __device__ int64_t off_obs() const { return off_trf() + 8 * epad * N * (int64_t)sizeof(T); }
-    __host__ __device__ int64_t bytes() const { return off_obs() + 2 * epad * (5 + 3 * (int64_t)N) * (int64_t)sizeof(T); }
-    __device__ __forceinline__ PoolHeader<T>* header() const { return reinterpret_cast<PoolHeader<T>*>(base); }
-    __device__ __forceinline__ uint32_t* counters() const { return reinterpret_cast<uint32_t*>(base); }
-    // request bits: per window of 256 envs sixteen words, slot 0's eight then slot 1's (one s_load_dwordx16)
-    __device__ __forceinline__ uint32_t* req_word(int s, int64_t e) const {
-        return reinterpret_cast<uint32_t*>(base + kPoolHeader) + ((e >> 8) * 16 + s * 8 + ((e >> 5) & 7));
-    }
-    __device__ __forceinline__ uint32_t* req_ep(int s) const { return reinterpret_cast<uint32_t*>(base + off_req_ep()) + s * epad; }
-    __device__ __forceinline__ uint2* tag(int s) const { return reinterpret_cast<uint2*>(base + off_tag()) + s * epad; }
-    __device__ __forceinline__ T* own_psi(int s) const { return reinterpret_cast<T*>(base + off_own_psi()) + s * epad; }
-    // field f = 0..3 (x, y, psi, v), env-major [epad][N] like the live traffic block
-    __device__ __forceinline__ T* trf(int f, int s) const { return reinterpret_cast<T*>(base + off_trf()) + (int64_t)(s * 4 + f) * epad * N; }
-    __device__ __forceinline__ T* obs(int s) const { return reinterpret_cast<T*>(base + off_obs()) + (int64_t)s * epad * (5 + 3 * N); }
-};
-
-// Episode `r` of env `e` (index within this shard) into slot r & 1, by the lanes of one reset slot
-// (ResetSlots<NS>: lane `ent` of the slot = entity `ent`, 0 the player, n + 1 traffic n) -- the per-lane
-// functions of wave_reset_slots(), so the pooled episode equals the one generated inside a step bit for
-// bit.  Whole wave; `have`, `e`, `r` are uniform within a slot.
-template <typename T, bool FAST, int NS, typename R>
-__device__ __forceinline__ void pool_generate(const Params<T>& p, const ResetParamsT<R>& rp, const PoolView<T>& pool,
-                                              uint32_t k0, uint32_t k1, uint32_t key, int64_t env_offset, bool have,
-                                              int e, uint32_t r, int lane) {
+// ---- speculative reset (Acas2dState.hint) ---------------------------------------------------------------
+// Re-initialising a finished env is ACAS2DGame.__init__ (game.py:80-116: one RNG block per aircraft) plus the
+// new episode's first observe() (environment.py:44-48): ~600 dependent instructions at the very END of the
+// launch, on the wave every other wave then waits for (the launch ends with its slowest wave; measured at
+// 65 536 x 8: 5.9 us per launch against 4.7 us when nothing ever finishes -- RNG + first observation 0.6 us,
+// moving the new state into place 0.5 us).  Which envs CAN finish at step t + 1 is known at step t: the player
+// and the traffic move by exactly v dt per step, so an env whose aircraft are all further than the collision
+// distance + (v + v_k) dt apart, whose goal is further than the goal radius + v dt away and whose step counter
+// is below the limit cannot finish (hint helpers above).  Every step leaves that flag in hint[e] (about 1 % of
+// the envs at the default configuration); the next step loads hint and episode FIRST and, while the rest of its
+// loads are in flight and the vector ALUs would idle, generates the next episode of every flagged env -- up to
+// SLOTS of them side by side, lane `ent` of a slot = entity `ent`, the same per-lane functions as
+// wave_reset_slots(), hence the same bits -- into the wave's reset slots in LDS: state, first observation,
+// hint.  A finished env whose slot is there is re-initialised by the commit in step_kernel (LDS reads, the row
+// swap, register selects); anything else -- hint not maintained by the caller's path, more flagged envs than
+// slots -- takes wave_reset_slots() as before.  Results never depend on hint[]: it only decides which path
+// produces them.
+template <typename T, bool FAST, int NS, int G, typename R>
+__device__ __forceinline__ unsigned long long spec_generate(const Params<T>& p, const ResetParamsT<R>& rp, uint32_t k0,
+                                                            uint32_t k1, uint64_t gid_wave, unsigned long long cm, int lane,
+                                                            uint32_t episode_lane, T* __restrict__ slots, int& src_out) {
     using RS = ResetSlots<NS>;
-    constexpr int N = NS, D = 5 + 3 * NS;
-    const int ent = lane % RS::STRIDE;
-    const int sl = (int)(r & 1u);
-    const uint64_t gid = (uint64_t)(env_offset + (int64_t)e);
+    using SL = SlotLayout<T, NS>;
+    constexpr int N = NS;
+    const int slot = lane / RS::STRIDE, ent = lane % RS::STRIDE;
+    unsigned long long taken = 0;
+    int src = -1;                                         // the lane of my slot's env's group leader
+    uint32_t episode_prev = 0;
+    for (int k = 0; k < RS::SLOTS && cm != 0; ++k) {       // slot k <- the k-th flagged env; wave-uniform
+        const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
+        cm &= cm - 1;
+        taken |= 1ull << b;
+        const uint32_t ep_b = (uint32_t)lane_value((int)episode_lane, b);
+        if (slot == k) { src = b; episode_prev = ep_b; }
+    }
+    src_out = src;
+    const bool have = src >= 0;
+    const int e = (src & 63) / G;                         // my slot's env (in the wave)
+    T* sk = slots + slot * SL::STRIDE;
+    const uint64_t gid = gid_wave + (uint64_t)e;
     T tx = T(0), ty = T(0), tpsi = T(0), tv = T(0);
     const bool mine = have && ent <= N;
-    if (mine) reset_entity<T, R>(rp, k0, k1, (uint32_t)gid, (uint32_t)(gid >> 32), r, ent, tx, ty, tpsi, tv);
-    const T psi_own = __shfl(tpsi, lane & ~(RS::STRIDE - 1), 64);      // the slot's player heading
+#ifdef ACAS2D_EXP_GEN_FAKE
+    if (mine) {     // timing experiment: a plausible episode at no cost (what an off-path generator would leave behind)
+        tx = T(800) + T(37) * ent; ty = T(100) + T(90) * ent; tpsi = T(40) * ent; tv = T(200);
+        if (ent >= 1) { const int n = ent - 1; sk[n] = tx; sk[N + n] = ty; sk[2 * N + n] = tpsi; sk[3 * N + n] = tv;
+                        sk[SL::OBS + 5 + 3 * n] = T(0.1); sk[SL::OBS + 6 + 3 * n] = T(0.2); sk[SL::OBS + 7 + 3 * n] = T(0.3); }
+        else { sk[SL::OWN_PSI] = T(0); sk[SL::HINT] = T(0); sk[SL::OBS] = T(0.001); sk[SL::OBS + 1] = T(0); sk[SL::OBS + 2] = T(0); sk[SL::OBS + 3] = T(0.4); sk[SL::OBS + 4] = T(0); }
+    }
+    return taken;
+#endif
+    if (mine) reset_entity<T, R>(rp, k0, k1, (uint32_t)gid, (uint32_t)(gid >> 32), episode_prev + 1u, ent, tx, ty, tpsi, tv);
+    const T psi_own = __shfl(tpsi, lane & ~(RS::STRIDE - 1), 64);         // the slot's player heading
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
     const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
+    bool near = false;
     if (mine) {
-        T* obs = pool.obs(sl) + (int64_t)e * D;
         if (ent >= 1) {
-            const int64_t i = (int64_t)e * N + (ent - 1);
-            pool.trf(0, sl)[i] = tx; pool.trf(1, sl)[i] = ty; pool.trf(2, sl)[i] = tpsi; pool.trf(3, sl)[i] = tv;
+            const int n = ent - 1;
+            sk[n] = tx; sk[N + n] = ty; sk[2 * N + n] = tpsi; sk[3 * N + n] = tv;
             T d, dca, vc;
-            traffic_step<T, FAST>(p, c, false, tx, ty, tpsi, tv, d, dca, vc);     // environment.py:44-48: first observe()
-            put_traffic_obs<T, FAST>(p, obs + 5 + 3 * (ent - 1), d, dca, vc);
+            traffic_step<T, FAST>(p, c, false, tx, ty, tpsi, tv, d, dca, vc);      // environment.py:44-48: first observe()
+            put_traffic_obs<T, FAST>(p, sk + SL::OBS + 5 + 3 * n, d, dca, vc);
+            near = d < m_fma(tv, hint_dt(p), hint_collision_base(p, c.v));
         } else {
-            pool.own_psi(sl)[e] = tpsi;
-            put_own_obs<T, FAST>(p, obs, 1, o.psi, c);
-            pool.tag(sl)[e] = make_uint2(r, key);
+            sk[SL::OWN_PSI] = tpsi;
+            put_own_obs<T, FAST>(p, sk + SL::OBS, 1, o.psi, c);
         }
     }
-}
-
-// A struct of 4-byte-aligned members out of the constant address space, dword by dword (scalar loads).
-template <typename S>
-__device__ __forceinline__ S load_const(const S ACAS2D_AS4* src) {
-    static_assert(sizeof(S) % 4 == 0, "dword-sized struct");
-    union { S s; uint32_t w[sizeof(S) / 4]; } u;
-    const uint32_t ACAS2D_AS4* sp = (const uint32_t ACAS2D_AS4*)src;
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(S) / 4; ++i) u.w[i] = sp[i];
-    return u.s;
-}
-
-// One helper wave of a step launch: the refill requests of envs [hw * 256, hw * 256 + 256).  Everything it
-// needs comes from the pool itself by scalar loads (header, request words), which do not queue behind the
-// chip-wide burst of vector loads the stepping waves start the launch with.
-template <typename T, bool FAST, int NS>
-__device__ __forceinline__ void pool_helper_wave(unsigned char* base, uint32_t epad, uint32_t key, uint32_t flags,
-                                                 int64_t hw, int lane) {
-    using RS = ResetSlots<NS>;
-    const PoolView<T> pool{base, (int64_t)epad, NS};
-    const PoolHeader<T> ACAS2D_AS4* hd = (const PoolHeader<T> ACAS2D_AS4*)base;
-    const int64_t n_envs = hd->n_envs, w0 = hw * kPoolWindow;
-    // a header written for another seed / shard / configuration (or never written): nothing useful to generate
-    if (hd->key != key || hd->n_traffic != (uint32_t)NS || w0 >= n_envs) return;
-    const uint32_t ACAS2D_AS4* bw = (const uint32_t ACAS2D_AS4*)pool.req_word(0, w0);
-    uint32_t w = 0;                                        // lane k < 16: word k of the window (slot k >> 3)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const uint32_t sw = bw[k]; w = lane == k ? sw : w; }
-    unsigned long long m = __ballot(w != 0u);
-    if (m == 0) return;
-    const Params<T> p = load_const(&hd->p);
-    const ResetParamsT<T> rp = load_const(&hd->rp);
-    const uint32_t k0 = hd->k0, k1 = hd->k1;
-    const int64_t env_offset = hd->env_offset;
-    const int slot = lane / RS::STRIDE;
-    while (m) {                                            // wave-uniform; almost always one trip
-        int my_e = 0, my_s = 0;
-        uint32_t r = 0u;
-        bool have = false;
-        for (int k = 0; k < RS::SLOTS && m != 0; ++k) {    // reset slot k <- the next pending request
-            const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-            uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, L);
-            const int b = __ffs((int)wl) - 1;
-            wl &= wl - 1u;
-            if (lane == L) w = wl;
-            if (wl == 0u) m &= m - 1ull;
-            const int e_k = (int)w0 + ((L & 7) << 5) + b, s_k = L >> 3;
-            const uint32_t r_k = ((const uint32_t ACAS2D_AS4*)pool.req_ep(s_k))[e_k];     // scalar load
-            if (slot == k) { my_e = e_k; my_s = s_k; r = r_k; have = true; }
-        }
-        // a request names its slot by the parity of its episode; anything else is debris and is dropped
-        const bool ok = have && r != 0u && (int)(r & 1u) == my_s && my_e < n_envs;
-        pool_generate<T, FAST, NS>(p, rp, pool, k0, k1, key, env_offset, ok, my_e, r, lane);
-        if (have && lane % RS::STRIDE == 0) {
-            pool.req_ep(my_s)[my_e] = 0u;
-            atomicAnd(pool.req_word(my_s, my_e), ~(1u << (my_e & 31)));
-            if (ok && (flags & 1u)) atomicAdd(pool.counters() + 2, 1u);
-        }
+    const unsigned long long nb = __ballot(near);
+    if (mine && ent == 0) {
+        const unsigned long long mine_bits = (nb >> (slot * RS::STRIDE)) & ((RS::STRIDE == 64) ? ~0ull : ((1ull << RS::STRIDE) - 1ull));
+        sk[SL::HINT] = (mine_bits != 0 || may_reach_goal(p, c.v, c.d_goal) || 1 >= p.max_steps) ? T(1) : T(0);
     }
+    return taken;
 }
-
-// Can this lane's traffic end the env's episode in THIS step?  Conservative: the player has already
-// moved (o.x, o.y), an aircraft still moves by exactly v dt (aircraft.py:24-25), so its distance after
-// the move is at least the distance now minus v dt; the slack covers every rounding on the way.  NaN
-// state compares false here exactly as in detect_collisions (game.py:185-189).
-template <typename T, int C>
-__device__ __forceinline__ bool may_collide(const Params<T>& p, const Own<T>& o, const Traffic<T, C>& tr) {
-    bool any = false;
-    const T dts = p.dt * T(1.0001), base = p.collision_dist + T(0.01);
-    if constexpr (sizeof(T) == 4 && C % 2 == 0) {
-#pragma unroll
-        for (int k = 0; k < C; k += 2) {
-            const F2 dx = F2{tr.x.v[k], tr.x.v[k + 1]} - o.x, dy = F2{tr.y.v[k], tr.y.v[k + 1]} - o.y;
-            const F2 thr = m_fma(F2{tr.v.v[k], tr.v.v[k + 1]}, F2{dts, dts}, F2{base, base});
-            const F2 d2 = m_fma(dy, dy, dx * dx), t2 = thr * thr;
-            any |= (d2.x < t2.x) | (d2.y < t2.y);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-            const T dx = tr.x.v[k] - o.x, dy = tr.y.v[k] - o.y;
-            const T thr = m_fma(tr.v.v[k], dts, base);
-            any |= m_fma(dy, dy, dx * dx) < thr * thr;
-        }
-    }
-    return any;
-}
-
-// What a stepping wave fetched from the pool for the envs that may finish in this step.
-constexpr int kPoolRows = 4;          // first observations prefetched per wave (more candidates: slow path)
-template <typename T, int C, int G, int NS>
-struct PoolFetch {
-    Traffic<T, C> tr;                 // owner lanes: their part of the next episode's traffic block
-    T own_psi;
-    uint32_t tag_ep, tag_key;
-    T row[kPoolRows];                 // lane i: entry i of the next first observation of candidate q
-    unsigned long long cm;            // candidate envs (bit = lane of the group leader)
-    bool cand;
-
-    __device__ __forceinline__ void fetch(const Params<T>& p, const PoolView<T>& pool, const Own<T>& o, const OwnCtx<T>& c,
-                                          const Traffic<T, C>& live, int32_t steps, uint32_t episode, int64_t e_wave,
-                                          int el, int j, int lane, bool active) {
-        constexpr int N = NS, D = 5 + 3 * NS;
-        using V = Vec<T, C>;
-        // game.py:294-314: timeout and goal are known exactly already, only the collision needs the bound
-        const bool mine = may_collide<T, C>(p, o, live) | (c.d_goal < p.goal_radius) | (steps > p.max_steps);
-        cand = active && group_or<G>((int)mine) != 0;
-        cm = __ballot(cand && j == 0);
-        tag_ep = 0u; tag_key = 0u; own_psi = T(0);
-        if (cm != 0) {                                     // wave-uniform: ~1 wave in 5 at 65 536 x 8
-            const int sl = (int)((episode + 1u) & 1u);     // the slot that holds episode + 1
-            if (cand) {
-                const int64_t e = e_wave + el, i0 = e * N + j * C;
-                tr.psi = *reinterpret_cast<const V*>(pool.trf(2, sl) + i0);
-                tr.v = *reinterpret_cast<const V*>(pool.trf(3, sl) + i0);
-                tr.x = *reinterpret_cast<const V*>(pool.trf(0, sl) + i0);
-                tr.y = *reinterpret_cast<const V*>(pool.trf(1, sl) + i0);
-                own_psi = pool.own_psi(sl)[e];
-                const uint2 tg = pool.tag(sl)[e];
-                tag_ep = tg.x; tag_key = tg.y;
-            }
-            unsigned long long rm = cm;
-#pragma unroll
-            for (int q = 0; q < kPoolRows; ++q) {
-                if (rm != 0) {
-                    const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)rm) - 1);
-                    rm &= rm - 1ull;
-                    const int sq = __builtin_amdgcn_readlane(sl, b);
-                    if (lane < D) row[q] = (pool.obs(sq) + (e_wave + b / G) * D)[lane];
-                }
-            }
-        }
-    }
-};
 
 // Flush the wave's LDS tile (`count` values, the contiguous slice dst[0 .. count) of obs[E][D])
 // with lane-linear stores: 16 bytes per lane where the slice is 16-byte aligned, else one value.
@@ -1470,18 +1350,18 @@ __device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&
 // arithmetic is this same code, so rollout(T) == T x step() bit for bit.
 // With POLICY (rollout, one lane per env) the action of every step comes from policy_action() on the
 // previous observation instead of from actions[t][E], which becomes an output.
-// With POOL (per-step launch, packed shape, auto-reset) the last pk.helper_blocks workgroups refill the
-// episode pool and the stepping waves take finished envs' next episodes from it (see "the episode pool").
+// With SPEC (per-step launch, packed shape, auto-reset, Acas2dState.hint given) the next episode of every env
+// the previous step flagged is generated while the wave's loads are in flight (see "speculative reset").
 template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false,
-          bool POOL = false>
+          bool SPEC = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
-                                                      int tile_elems, int n_steps, PolicyW pw, PoolArg pk) {
+                                                      int tile_elems, int n_steps, PolicyW pw) {
     static_assert(!ROLLOUT || (AUTO_RESET && PACKED), "rollout: auto-reset semantics, packed shapes");
     static_assert(!POLICY || (ROLLOUT && G == 1), "in-kernel policy: rollout mode, one lane per env");
-    static_assert(!POOL || (PACKED && AUTO_RESET && !ROLLOUT && ResetSlots<C * G>::SLOTS >= 2 && 5 + 3 * C * G <= 64),
-                  "episode pool: per-step launch, packed shape, auto-reset, N + 1 <= 32, obs row within a wave");
+    static_assert(!SPEC || (PACKED && AUTO_RESET && !ROLLOUT && ResetSlots<C * G>::SLOTS >= 2),
+                  "speculative reset: per-step launch, packed shape, auto-reset, N + 1 <= 32");
     constexpr int NS = PACKED ? C * G : 0;         // packed shapes: n_traffic is a compile-time constant
     const int N = PACKED ? NS : N_arg;
     constexpr int EPW = 64 / G;                    // envs per wavefront
@@ -1493,24 +1373,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         asm volatile("" :: "s"(nb), "s"(n_envs), "s"(s_arg.own_x), "s"(s_arg.own_y), "s"(s_arg.own_psi), "s"(s_arg.own_v),
                      "s"(s_arg.goal_x), "s"(s_arg.goal_y), "s"(s_arg.trf_x), "s"(s_arg.trf_y), "s"(s_arg.trf_psi),
                      "s"(s_arg.trf_v), "s"(s_arg.steps), "s"(s_arg.total_reward), "s"(s_arg.episode), "s"(io_arg.actions),
-                     "s"(tile_elems), "s"(pk.helper_blocks));
+                     "s"(tile_elems), "s"(s_arg.hint));
     }
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
     const int wib = wave_in_block();
-    const uint32_t helpers = POOL ? (uint32_t)pk.helper_blocks : 0u;
-    const PoolView<T> pool{pk.base, (int64_t)pk.epad, NS};
-    if constexpr (POOL) {
-        // The LAST workgroups of the grid refill pool slots and step nothing: dispatched behind the stepping
-        // workgroups, their waves are the youngest on their SIMDs and yield the issue slots to the stepping
-        // waves (arbitration is by age), and their short chain still ends well before the launch does.
-        if (blockIdx.x >= gridDim.x - helpers) {
-            pool_helper_wave<T, FAST, NS>(pk.base, pk.epad, pk.key, pk.flags,
-                                          (int64_t)(blockIdx.x - (gridDim.x - helpers)) * kWavesPerBlock + wib, lane);
-            return;
-        }
-    }
-    const int64_t wave = remap_block(helpers) * kWavesPerBlock + wib;
+    const int64_t wave = remap_block() * kWavesPerBlock + wib;
     const int64_t e_wave = wave * EPW;             // first env of this wave (scalar)
     if (e_wave >= n_envs) return;                  // whole wave idle
     const int D = 5 + 3 * N;
@@ -1519,16 +1387,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     const State<T> s = rebase(s_arg, e_wave, N);   // everything below indexes envs by `el`
     const StepIO<T> io0 = rebase(io_arg, e_wave, D);
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    // per wave: the observation tile, then (HANDOFF) 4N+1 values of reset hand-off scratch
+    // per wave: the observation tile, then (HANDOFF) the reset slots (SlotLayout) / one 4N+1-value scratch
     constexpr bool HANDOFF = PACKED && AUTO_RESET;   // finished envs are reset BEFORE the wave's stores
     T* tile = reinterpret_cast<T*>(lds_raw) + wib * tile_elems;
     T* row = tile + el * D;
-    T* scratch = HANDOFF ? tile + EPW * D : nullptr;
+    T* scratch = HANDOFF ? tile + (EPW * D + 3) / 4 * 4 : nullptr;     // 16-byte aligned within the tile allocation
 
     ACAS2D_STAMP(0, wave, lane, false);
     ACAS2D_STAMP(1, wave, lane, false);
     int32_t steps = 0;
     uint32_t episode = 0;
+    uint32_t hint_in = 0;
     T total = T(0);
     Own<T> o{};
     Traffic<T, C> tr{};
@@ -1542,14 +1411,21 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     const bool run = PACKED ? true : active;
     const int el_l = (PACKED && !active) ? 0 : el;         // the env a lane LOADS
     if (run) {
-        // ---- every load of this lane up front: one memory round trip, all requests in flight.  The
-        // player's scalars and the action first, the traffic vectors (the bulk) last: loads return in
-        // order, so the player-side arithmetic can start while the vectors are still landing
+        // ---- every load of this lane up front: one memory round trip, all requests in flight.  SPEC: the
+        // hint and the episode counter first -- loads return in order, and the speculative generation below
+        // needs nothing else.  Then the player's scalars and the action, the traffic vectors (the bulk) last:
+        // the player-side arithmetic can start while the vectors are still landing
         // (s_waitcnt vmcnt(4), then vmcnt(0) before the first traffic instruction): 7.12 -> 7.0x us.
+        if constexpr (SPEC) {
+            hint_in = s.hint[el_l];
+            episode = s.episode[el_l];
+            asm volatile("" ::: "memory");                 // issued before everything below (a compiler fence only:
+                                                           // naming the values here would WAIT for them first)
+        }
         o = Own<T>{s.own_x[el_l], s.own_y[el_l], s.own_psi[el_l], s.own_v[el_l], T(0), s.goal_x[el_l], s.goal_y[el_l]};
         steps = s.steps[el_l];
         total = s.total_reward[el_l];
-        if constexpr (AUTO_RESET) episode = s.episode[el_l];
+        if constexpr (AUTO_RESET) { if constexpr (!SPEC) episode = s.episode[el_l]; }
         else frozen = s.status[el_l] != 0;                                 // game.py:243-245
         if constexpr (!POLICY) action_next = io0.actions[el_l];
         if constexpr (PACKED) tr = load_traffic<T, C>(s, el_l * N + j * C);
@@ -1569,9 +1445,24 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                      "s"(rp.tn_y_max), "s"(rp.speed_factor_min), "s"(rp.speed_factor_max), "s"(rp.airspeed),
                      "s"(k0), "s"(k1), "s"(io_arg.ep_steps));
     }
+    // ---- SPEC: the next episodes of the flagged envs, generated while the rest of the loads are in flight
+    unsigned long long spec_mask = 0;                      // envs with a generated slot (bit = group leader's lane)
+    int spec_src = -1;                                     // per lane: the group leader's lane of my slot's env
+    if constexpr (SPEC) {
+#ifdef ACAS2D_EXP_NO_EARLY
+        const unsigned long long cm = 0;
+#else
+        const unsigned long long cm = __ballot(active && hint_in != 0 && j == 0);
+#endif
+        if (cm != 0)                                       // wave-uniform: about one wave in five at 65 536 x 8
+#ifdef ACAS2D_EXP_GEN_EMPTY
+            spec_mask = 0;
+        else
+#endif
+            spec_mask = spec_generate<T, FAST, NS, G>(p, rp, k0, k1, (uint64_t)(env_offset + e_wave), cm, lane, episode,
+                                                      scratch, spec_src);
+    }
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
-    PoolFetch<T, C, G, NS> pf;                             // POOL only
-    pf.cm = 0; pf.cand = false;
     const int T_steps = ROLLOUT ? n_steps : 1;
     if constexpr (POLICY) {
         // the observation the first action is taken on (reset()'s / the previous step's) into the lane's row
@@ -1587,7 +1478,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                            io0.ep_steps ? io0.ep_steps + te : nullptr};
         const bool last = !ROLLOUT || t == T_steps - 1;
         uint8_t oc = 0;
-        T rw_out = T(0);
+        bool hint_out = false;                             // SPEC: may this env finish at the NEXT step
         T action = action_next;
         if constexpr (POLICY) {
             constexpr int DP = 5 + 3 * NS;                // compile-time obs width (packed shapes)
@@ -1629,14 +1520,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // `episode` is first USED in the reset loop far below; without this use the compiler waits
             // for its load there with s_waitcnt vmcnt(0) -- i.e. for every store issued since.
             asm volatile("" : "+v"(episode));
-            // POOL: between the player side and the traffic side, fetch the next episodes of the envs that may finish
             T d_sep = T(0);                               // record rows only
-            auto pool_fetch = [&](const OwnCtx<T>& c) {
-                if constexpr (POOL) pf.fetch(p, pool, o, c, tr, steps, episode, e_wave, el, j, lane, active);
+            auto before_traffic = [&](const OwnCtx<T>&) {
                 if constexpr (!AUTO_RESET) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); }
             };
-            Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
-                                                       ROLLOUT ? &trig : nullptr, pool_fetch);
+            Seen<T> r = observe<T, C, G, PACKED, FAST, SPEC>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
+                                                             ROLLOUT ? &trig : nullptr, before_traffic);
 
             // game.py:249-292 evaluate()
             T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
@@ -1654,13 +1543,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
             total = total + rw;                                               // :287
             if (!active) oc = 0;                          // a padding lane never finishes anything
-            rw_out = rw;
+            if constexpr (SPEC) hint_out = r.near || may_reach_goal(p, o.v, r.d_goal) || steps >= p.max_steps;
             if (j == 0 && active) {
-                if constexpr (!POOL) {                    // (POOL: stored behind the pool commit, see there)
-                    io.reward[el] = rw;
-                    io.done[el] = oc != 0;
-                    io.outcome[el] = oc;
-                }
+                io.reward[el] = rw;
+                io.done[el] = oc != 0;
+                io.outcome[el] = oc;
                 if constexpr (!HANDOFF) {
                     if (last && (oc == 0 || !AUTO_RESET)) {
                         s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
@@ -1681,82 +1568,86 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // ONE tile flush below.  (Resetting after the flush cost a second store round at the very
             // end of the kernel -- ~12 scattered 4-byte stores per entity lane plus a re-flush of the
             // row: 0.8 us of the 7.7 us launch at 65 536 x 8.)
-            bool fresh = false;
+            bool fresh = false, fresh_const = false;
             unsigned long long dm = __ballot(oc != 0 && j == 0);
-            if constexpr (POOL) {
-                // ---- pool commit: a finished env whose next episode was fetched (right tag) takes it by
-                // register selects; its row of the tile is swapped for the fetched first observation.
-                if ((dm & pf.cm) != 0) {
-                    const int rank = __popcll(pf.cm & ((1ull << (el * G)) - 1ull));      // my env among the candidates
-                    const bool fast = oc != 0 && pf.cand && rank < kPoolRows && pf.tag_ep == episode + 1u && pf.tag_key == pk.key;
-                    const unsigned long long fm = __ballot(fast && j == 0);
-                    if (fm != 0) {
-                        // one wait for everything fetched, here: the only younger memory operations are the
-                        // traffic-block stores issued early in observe() (the per-env outputs follow below)
+            if constexpr (SPEC) {
+                // ---- commit: a finished env whose next episode was generated in the load shadow takes it from its
+                // slot -- one batch of LDS reads, the row swap, register selects; nothing is computed here.
+                const unsigned long long fm = dm & spec_mask;
+                if (dm != 0 && fm != 0) {
+                    using SL = SlotLayout<T, NS>;
+                    using RS = ResetSlots<NS>;
+                    wave_lds_fence();                     // every row of the tile and every slot is complete
+                    // slot lanes: the finished episode's last observation out, the new episode's first one in
+                    const int slot = lane / RS::STRIDE, ent = lane % RS::STRIDE;
+                    const bool swap = spec_src >= 0 && ((fm >> (spec_src & 63)) & 1ull) != 0;
+                    const int e_s = (spec_src & 63) / G;
+                    T* row_s = tile + e_s * D;
+                    const T* slot_s = scratch + slot * SL::STRIDE;
+                    constexpr int PASSES = (5 + 3 * NS + RS::STRIDE - 1) / RS::STRIDE;
+                    T old_v[PASSES], new_v[PASSES];
 #pragma unroll
-                        for (int q = 0; q < kPoolRows; ++q) asm volatile("" : "+v"(pf.row[q]));
-                        wave_lds_fence();                 // every row of the tile is complete
-                        unsigned long long rm = pf.cm;
-#pragma unroll
-                        for (int q = 0; q < kPoolRows; ++q) {
-                            if (rm != 0) {
-                                const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)rm) - 1);
-                                rm &= rm - 1ull;
-                                if ((fm >> b) & 1ull) {
-                                    T* rq = tile + (b / G) * D;
-                                    if (lane < D) {
-                                        const T last_obs = rq[lane];
-                                        if (io.term_obs) (io.term_obs + (b / G) * D)[lane] = last_obs;
-                                        rq[lane] = pf.row[q];                 // environment.py:44-48: the new episode's first observation
-                                    }
-                                }
-                            }
-                        }
-                        wave_lds_fence();                 // the fresh rows are complete
-                        if (fast) {
-                            if (j == 0) {
-                                if (io.ep_return) io.ep_return[el] = total;
-                                if (io.ep_steps) io.ep_steps[el] = steps;
-                            }
-                            tr = pf.tr;
-                            o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, pf.own_psi, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-                            steps = 1;                                            // environment.py:47
-                            total = T(0);
-                            episode += 1u;
-                            fresh = true;
-                            using V = Vec<T, C>;
-                            const int i0 = el * N + j * C;
-                            *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
-                            *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
-                        }
-                        dm &= ~fm;
-                        if ((pk.flags & 1u) && lane == 0) atomicAdd(pool.counters() + 0, (uint32_t)__popcll(fm));
+                    for (int q = 0; q < PASSES; ++q) {
+                        const int i = ent + q * RS::STRIDE;
+                        const bool ok = swap && i < D;
+                        old_v[q] = ok ? row_s[i] : T(0);
+                        new_v[q] = ok ? slot_s[SL::OBS + i] : T(0);
                     }
+                    // owner lanes: their part of the new traffic block, the player's heading, the new episode's hint
+                    const bool mine = ((fm >> (lane & ~(G - 1))) & 1ull) != 0;
+                    const int k_own = __popcll(spec_mask & ((1ull << (lane & ~(G - 1))) - 1ull));
+                    const T* slot_o = scratch + (mine ? k_own : 0) * SL::STRIDE;
+                    using V = Vec<T, C>;
+                    Traffic<T, C> nt;
+                    nt.x = *reinterpret_cast<const V*>(slot_o + j * C);
+                    nt.y = *reinterpret_cast<const V*>(slot_o + NS + j * C);
+                    nt.psi = *reinterpret_cast<const V*>(slot_o + 2 * NS + j * C);
+                    nt.v = *reinterpret_cast<const V*>(slot_o + 3 * NS + j * C);
+                    const T n_psi = slot_o[SL::OWN_PSI], n_hint = slot_o[SL::HINT];
+                    wave_lds_fence();                     // the reads above precede the row rewrite
+#pragma unroll
+                    for (int q = 0; q < PASSES; ++q) {
+                        const int i = ent + q * RS::STRIDE;
+                        if (swap && i < D) {
+                            if (io.term_obs) (io.term_obs + e_s * D)[i] = old_v[q];
+                            row_s[i] = new_v[q];          // environment.py:44-48: the new episode's first observation
+                        }
+                    }
+                    if (mine) {
+                        if (j == 0) {
+                            if (io.ep_return) io.ep_return[el] = total;
+                            if (io.ep_steps) io.ep_steps[el] = steps;
+                        }
+                        fresh_const = o.v == (T)rp.own_v && o.gx == (T)rp.goal_x && o.gy == (T)rp.goal_y;
+                        tr = nt;
+                        o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, n_psi, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+                        steps = 1;                                            // environment.py:47
+                        total = T(0);
+                        episode += 1u;
+                        fresh = true;
+                        hint_out = n_hint != T(0);
+                        const int i0 = el * N + j * C;
+                        *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+                        *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
+                    }
+                    dm &= ~fm;
+                    if (s.stats && lane == 0) atomicAdd(s.stats + 0, (uint32_t)__popcll(fm));
                 }
-                if ((pk.flags & 1u) && dm != 0 && lane == 0) atomicAdd(pool.counters() + 1, (uint32_t)__popcll(dm));
-            }
-            if constexpr (POOL) {
-                // reward / done / outcome leave only now: issued before the commit they would stand between the
-                // pool loads and their wait (vmcnt retires in order), and the commit would wait for their
-                // acknowledgements
-                if (j == 0 && active) {
-                    io.reward[el] = rw_out;
-                    io.done[el] = oc != 0;
-                    io.outcome[el] = oc;
-                }
+                if (dm != 0 && s.stats && lane == 0) atomicAdd(s.stats + 1, (uint32_t)__popcll(dm));
             }
             constexpr bool SLOTTED = ResetSlots<NS>::SLOTS >= 2;      // N + 1 <= 32: several envs per pass
             if constexpr (SLOTTED) {
+                using SL = SlotLayout<T, NS>;
                 while (dm) {
                     wave_lds_fence();                     // every row of the tile is complete
                     const unsigned long long taken =
                         wave_reset_slots<T, FAST, NS, G>(p, rp, io, k0, k1, (uint64_t)(env_offset + e_wave), dm, lane,
                                                          episode, tile, scratch);
                     dm &= ~taken;
-                    wave_lds_fence();                     // the fresh rows and the scratches are complete
+                    wave_lds_fence();                     // the fresh rows and the slots are complete
                     if ((taken >> (el * G)) & 1ull) {     // my env was reset: its owner group goes on with the new episode
                         const int k_own = __popcll(taken & ((1ull << (el * G)) - 1ull));
-                        const T* scr = scratch + k_own * (4 * NS + 1);
+                        const T* scr = scratch + k_own * SL::STRIDE;
                         if (j == 0) {
                             if (io.ep_return) io.ep_return[el] = total;
                             if (io.ep_steps) io.ep_steps[el] = steps;
@@ -1767,18 +1658,19 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                             tr.x.v[k] = scr[n]; tr.y.v[k] = scr[N + n];
                             tr.psi.v[k] = scr[2 * N + n]; tr.v.v[k] = scr[3 * N + n];
                         }
-                        o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, scr[4 * N], (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+                        o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, scr[SL::OWN_PSI], (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
                         steps = 1;                                            // environment.py:47
                         total = T(0);
                         episode += 1u;
                         fresh = true;
+                        hint_out = true;                  // not worked out on this path: "may finish" is always safe
                         trig.valid = false; trig.dirty = false;   // new headings (stored below)
                         using V = Vec<T, C>;
                         const int i0 = el * N + j * C;
                         *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
                         *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
                     }
-                    wave_lds_fence();                     // the scratches are free for the next pass
+                    wave_lds_fence();                     // the slots are free for the next pass
                 }
             }
             while (!SLOTTED && dm) {
@@ -1818,20 +1710,18 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             if (active && j == 0) {
                 if (fresh) {                              // per-episode constants of the new episode
                     s.episode[el] = episode;
-                    s.own_v[el] = o.v; s.goal_x[el] = o.gx; s.goal_y[el] = o.gy;
-                    if constexpr (POOL) {
-                        // the slot this reset used (or found stale) held episode `episode`; it is next read at this
-                        // env's next-but-one finish: ask the next launch's helper waves to put episode + 2 there
-                        const int64_t e = e_wave + el;
-                        pool.req_ep((int)(episode & 1u))[e] = episode + 2u;
-                        atomicOr(pool.req_word((int)(episode & 1u), e), 1u << (e & 31));
-                    }
+                    if (!fresh_const) { s.own_v[el] = o.v; s.goal_x[el] = o.gx; s.goal_y[el] = o.gy; }
                 }
                 if (last || fresh) {
                     s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
                     s.steps[el] = steps;
                     s.total_reward[el] = total;
                 }
+#ifndef ACAS2D_EXP_NO_HINT_STORE
+                if constexpr (SPEC) s.hint[el] = hint_out ? 1 : 0;
+#else
+                if constexpr (SPEC) { if (hint_in == 77u) s.hint[el] = hint_out ? 1 : 0; }
+#endif
             }
         }
         // Flush the tile (generic walk: now, the stores drain while finished envs are reset below).
@@ -1865,14 +1755,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     ACAS2D_STAMP(7, wave, lane, false);
 }
 
-// ACAS2DEnv.reset(), environment.py:44-48 (do_init > 0: fresh episodes; == 0: keep the injected state;
-// < 0: leave the state alone), then -- POOL -- the pool slots of the selected envs for episode + 1, + 2.
-template <typename T, int C, int G, bool PACKED, bool FAST, bool POOL>
+// ACAS2DEnv.reset(), environment.py:44-48 (do_init != 0: fresh episodes; == 0: keep the injected state).
+// HINT (shapes whose step kernel can speculate): also the selected envs' "may finish at the next step" flags.
+template <typename T, int C, int G, bool PACKED, bool FAST, bool HINT>
 __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetParams rp, State<T> s_arg,
                                                        const uint8_t* __restrict__ mask, T* obs,
                                                        int do_init, uint32_t k0, uint32_t k1,
                                                        int64_t env_offset, int64_t n_envs, int N,
-                                                       int tile_elems, PoolArg pk) {
+                                                       int tile_elems) {
     constexpr int EPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;
@@ -1885,7 +1775,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
     const bool selected = e_wave + el < n_envs && (!mask || mask[e_wave + el]);
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T* row = reinterpret_cast<T*>(lds_raw) + wib * tile_elems + el * D;
-    if (selected && do_init >= 0) {
+    if (selected) {
         Own<T> o;
         Traffic<T, C> tr;
         int32_t steps;
@@ -1897,11 +1787,13 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
             o = Own<T>{s.own_x[el], s.own_y[el], s.own_psi[el], s.own_v[el], T(0), s.goal_x[el], s.goal_y[el]};
             steps = s.steps[el];
         }
+        bool hint_out = true;                              // no observation, no distances: "may finish" is always safe
         if (obs) {
             steps += 1;
             T d_sep = T(0);
             auto sep = [&](const OwnCtx<T>&) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); };
-            const Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row, true, nullptr, sep);
+            const Seen<T> r = observe<T, C, G, PACKED, FAST, HINT>(p, s, o, el, j, N, steps, false, tr, row, true, nullptr, sep);
+            if constexpr (HINT) hint_out = r.near || may_reach_goal(p, o.v, r.d_goal) || steps >= p.max_steps;
             if (s.trace && j == 0)                        // game.py:132-160: the records' first entries
                 write_trace<T, FAST>(p, s.trace + el * kTraceWidth, o.psi, d_sep, T(0), r.h_goal, r.d_goal, r.d_dev, r.v_closing0,
                                      r.d_cpa0, step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev));
@@ -1913,46 +1805,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
             s.steps[el] = steps;
             s.total_reward[el] = T(0);
             s.status[el] = 0;
-        }
-    }
-    if constexpr (POOL) {
-        if (pk.base != nullptr) {                          // whole wave from here on
-            constexpr int NS = C * G;
-            using RS = ResetSlots<NS>;
-            const PoolView<T> pool{pk.base, (int64_t)pk.epad, NS};
-            const uint32_t ep = selected ? s.episode[el] : 0u;
-            if (blockIdx.x == 0 && threadIdx.x == 0) {     // what the step kernels' helper waves generate with
-                PoolHeader<T>* hd = pool.header();
-                hd->key = pk.key; hd->k0 = k0; hd->k1 = k1; hd->n_traffic = (uint32_t)NS;
-                hd->env_offset = env_offset; hd->n_envs = n_envs;
-                hd->p = p;
-                hd->rp = ResetParamsT<T>{(T)rp.own_x0, (T)rp.own_y0, (T)rp.own_v, (T)rp.own_heading0, (T)rp.own_heading_jitter,
-                                         (T)rp.goal_x, (T)rp.goal_y, (T)rp.t0_x, (T)rp.t0_y_base, (T)rp.t0_y_span,
-                                         (T)rp.t0_heading_base, (T)rp.t0_heading_step, (T)rp.t0_heading_jitter,
-                                         (T)rp.tn_x_max, (T)rp.tn_y_max, (T)rp.speed_factor_min, (T)rp.speed_factor_max,
-                                         (T)rp.airspeed};
-            }
-            if (selected && j == 0) {                      // pending refill requests of these envs are void now
-                const int64_t e = e_wave + el;
-                pool.req_ep(0)[e] = 0u; pool.req_ep(1)[e] = 0u;
-                atomicAnd(pool.req_word(0, e), ~(1u << (e & 31)));
-                atomicAnd(pool.req_word(1, e), ~(1u << (e & 31)));
-            }
-            unsigned long long sel = __ballot(selected && j == 0);
-            const int slot = lane / RS::STRIDE;
-            while (sel != 0) {                             // SLOTS envs per pass, two episodes each
-                int my_el = 0;
-                uint32_t my_ep = 0u;
-                bool have = false;
-                for (int k = 0; k < RS::SLOTS && sel != 0; ++k) {
-                    const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)sel) - 1);
-                    sel &= sel - 1ull;
-                    const uint32_t ep_b = (uint32_t)__builtin_amdgcn_readlane((int)ep, b);
-                    if (slot == k) { my_el = b / G; my_ep = ep_b; have = true; }
-                }
-                pool_generate<T, FAST, NS>(p, rp, pool, k0, k1, pk.key, env_offset, have, (int)e_wave + my_el, my_ep + 1u, lane);
-                pool_generate<T, FAST, NS>(p, rp, pool, k0, k1, pk.key, env_offset, have, (int)e_wave + my_el, my_ep + 2u, lane);
-            }
+            if constexpr (HINT) { if (s.hint) s.hint[el] = hint_out ? 1 : 0; }
         }
     }
 }
@@ -1960,12 +1813,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
 // ---- host-side launchers (instantiated per element type in acas2d_f32.hip / acas2d_f64.hip) ----
 struct Shape { int C, G; bool packed; };
 Shape choose_shape(int n_traffic, int elem_size);
-// shapes whose step kernel has a pooled variant (must agree with step_kernel's static_assert)
-// float32 only: the float64 parity build is bound by its libm transcendentals (25 us per launch at
-// 65 536 x 8), not by the reset tail, and its pooled variants ran out of SGPRs (200+ spilled to VGPR lanes).
-constexpr bool pool_shape_ok(int C, int G, bool packed, int elem_size) {
-    return elem_size == 4 && packed && C * G + 1 <= 32 && 5 + 3 * C * G <= 64;
-}
+// shapes whose step kernel has a speculating variant (must agree with step_kernel's static_assert)
+constexpr bool spec_shape_ok(int C, int G, bool packed) { return packed && C * G + 1 <= 32; }
 
 template <typename T>
 int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, uint32_t flags,

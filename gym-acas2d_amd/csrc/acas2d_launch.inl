@@ -39,45 +39,7 @@ template <typename T>
 static State<T> make_state(const Acas2dState& s) {
     return State<T>{(T*)s.own_x, (T*)s.own_y, (T*)s.own_psi, (T*)s.own_v, (T*)s.goal_x, (T*)s.goal_y,
                     (T*)s.trf_x, (T*)s.trf_y, (T*)s.trf_psi, (T*)s.trf_v, s.steps,
-                    (T*)s.total_reward, s.status, s.episode, (T*)s.trace};
-}
-
-// ---- the episode pool (Acas2dState.pool) -----------------------------------------------------------------
-static int64_t pool_epad(int64_t n_envs) { return (n_envs + kPoolWindow - 1) / kPoolWindow * kPoolWindow; }
-
-template <typename T>
-static int64_t pool_bytes_for(int64_t n_envs, int n_traffic) {
-    return PoolView<T>{nullptr, pool_epad(n_envs), n_traffic}.bytes();
-}
-
-// slots generated under another seed / shard offset / reset distribution must read as stale: FNV-1a of them
-static uint32_t pool_key(const Acas2dConfig& c, uint64_t seed, int64_t env_offset, int n_traffic) {
-    const ResetParams rp = make_reset_params<double>(c);
-    uint32_t h = 2166136261u;
-    auto mix = [&h](const void* ptr, size_t n) {
-        const unsigned char* b = (const unsigned char*)ptr;
-        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 16777619u; }
-    };
-    mix(&rp, sizeof(rp)); mix(&seed, sizeof(seed)); mix(&env_offset, sizeof(env_offset)); mix(&n_traffic, sizeof(n_traffic));
-    // the first observation stored with an episode depends on the normalisers and dt as well
-    mix(&c.dt, sizeof(double)); mix(&c.d_goal_max, 5 * sizeof(double)); mix(&c.max_steps, sizeof(c.max_steps));
-    return h ? h : 1u;
-}
-
-template <typename T>
-static PoolArg make_pool(const Acas2dConfig& c, const Acas2dState& st, const Shape& sh, uint64_t seed,
-                         int64_t env_offset, int64_t n_envs, int n_traffic) {
-    PoolArg pk{nullptr, 0u, 0u, 0, 0u};
-    if (!st.pool || !pool_shape_ok(sh.C, sh.G, sh.packed, (int)sizeof(T))) return pk;
-    pk.base = (unsigned char*)st.pool;
-    pk.epad = (uint32_t)pool_epad(n_envs);
-    pk.key = pool_key(c, seed, env_offset, n_traffic);
-    // one helper wave per kPoolWindow envs, in whole workgroups
-    const int64_t waves = pk.epad / kPoolWindow, blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    pk.helper_blocks = (int32_t)blocks;
-    if (const char* st_ = getenv("ACAS2D_POOL_STATS")) pk.flags = st_[0] == '1' ? 1u : 0u;
-    if (const char* hb = getenv("ACAS2D_POOL_HELPER_BLOCKS")) pk.helper_blocks = atoi(hb);   // diagnostic: 0 = nobody refills
-    return pk;
+                    (T*)s.total_reward, s.status, s.episode, (T*)s.trace, s.hint, s.stats};
 }
 
 static bool state_complete(const Acas2dState* s) {
@@ -101,11 +63,18 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
     const int64_t blocks = (n_envs + envs_per_block - 1) / envs_per_block;
     if (blocks > 0x7fffffffLL) { set_error("n_envs = %lld exceeds the grid limit", (long long)n_envs); return ACAS2D_EINVAL; }
     const int W = 16 / (int)sizeof(T);
-    // reset hand-off, per wave: one 4N+1-value scratch per reset slot (ResetSlots<N> in the kernels)
-    int64_t slots = 1;
-    if (sh.packed && n_traffic + 1 <= 32) { int stride = 2; while (stride < n_traffic + 1) stride *= 2; slots = 64 / stride; }
-    const int64_t scratch = sh.packed ? slots * (4 * (int64_t)n_traffic + 1) : 0;
-    const int64_t elems = ((epw * (5 + 3 * (int64_t)n_traffic) + scratch + W - 1) / W) * W;
+    // per wave: the observation tile, then the reset slots (SlotLayout<T, N> in the kernels; packed shapes with
+    // N + 1 <= 32) or one 4N+1-value hand-off scratch (the other packed shapes), everything 16-byte aligned
+    const int64_t tile = (epw * (5 + 3 * (int64_t)n_traffic) + 3) / 4 * 4;
+    int64_t scratch = 0;
+    if (sh.packed && n_traffic + 1 <= 32) {
+        int stride = 2; while (stride < n_traffic + 1) stride *= 2;
+        const int64_t obs_at = (4 * (int64_t)n_traffic + 2 + W - 1) / W * W;
+        scratch = (64 / stride) * ((obs_at + 5 + 3 * (int64_t)n_traffic + W - 1) / W * W);
+    } else if (sh.packed) {
+        scratch = 4 * (int64_t)n_traffic + 1;
+    }
+    const int64_t elems = ((tile + scratch + 3) / 4) * 4;
     const int64_t bytes = elems * kWavesPerBlock * (int64_t)sizeof(T);
     if (bytes > 64 * 1024) {
         set_error("n_traffic = %d needs a %lld-byte LDS observation tile per workgroup (limit 65536)", n_traffic, (long long)bytes);
@@ -118,21 +87,20 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
 template <typename T, int C, int G, bool PACKED>
 static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, const Params<T>& p,
                        const ResetParamsT<T>& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
-                       int64_t env_offset, int64_t n_envs, int N, const PoolArg& pk) {
-    if constexpr (pool_shape_ok(C, G, PACKED, (int)sizeof(T))) {
-        if (auto_reset && pk.base) {          // the pooled variant: pk.helper_blocks refill workgroups close the grid
-            hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false, false, true>),
-                               dim3(g.grid + (unsigned)pk.helper_blocks), dim3(kBlock), g.lds_bytes, stream,
-                               p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{}, pk);
+                       int64_t env_offset, int64_t n_envs, int N) {
+    if constexpr (spec_shape_ok(C, G, PACKED)) {
+        if (auto_reset && s.hint) {           // the speculating variant: next episodes generated in the load shadow
+            hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false, false, true>), dim3(g.grid), dim3(kBlock),
+                               g.lds_bytes, stream, p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
             return;
         }
     }
     if (auto_reset)
         hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{}, PoolArg{});
+                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
     else
         hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{}, PoolArg{});
+                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
 }
 
 template <typename T, int C, int G>
@@ -140,7 +108,7 @@ static void rollout_shape(const Geometry& g, hipStream_t stream, const Params<T>
                           const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
                           int64_t n_envs, int N, int n_steps) {
     hipLaunchKernelGGL((step_kernel<T, C, G, true, true, kFast, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, PolicyW{}, PoolArg{});
+                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, PolicyW{});
 }
 
 // the same with the SB3 actor evaluated in the kernel (thread-per-env shapes only)
@@ -149,15 +117,15 @@ static void policy_shape(const Geometry& g, hipStream_t stream, const Params<T>&
                          const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
                          int64_t n_envs, int N, int n_steps, const PolicyW& pw) {
     hipLaunchKernelGGL((step_kernel<T, C, 1, true, true, kFast, true, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, pw, PoolArg{});
+                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, pw);
 }
 
 template <typename T, int C, int G, bool PACKED>
 static void reset_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
                         const State<T>& s, const uint8_t* mask, T* obs, int do_init, uint32_t k0, uint32_t k1,
-                        int64_t env_offset, int64_t n_envs, int N, const PoolArg& pk) {
-    hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, kFast, pool_shape_ok(C, G, PACKED, (int)sizeof(T))>), dim3(g.grid), dim3(kBlock),
-                       g.lds_bytes, stream, p, rp, s, mask, obs, do_init, k0, k1, env_offset, n_envs, N, g.tile_elems, pk);
+                        int64_t env_offset, int64_t n_envs, int N) {
+    hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, kFast, spec_shape_ok(C, G, PACKED)>), dim3(g.grid), dim3(kBlock),
+                       g.lds_bytes, stream, p, rp, s, mask, obs, do_init, k0, k1, env_offset, n_envs, N, g.tile_elems);
 }
 
 static bool shape_instantiated(const Shape& sh) {
@@ -208,18 +176,16 @@ int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStep
                        (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const bool ar = (flags & ACAS2D_AUTO_RESET) != 0;
-    const PoolArg pk = make_pool<T>(*cfg, *st, sh, seed, env_offset, n_envs, n_traffic);
-    if (pk.base && ((uintptr_t)pk.base & 15u)) { set_error("acas2d_step: the pool must be 16-byte aligned"); return ACAS2D_EINVAL; }
     if (sh.packed) {
-#define X(C_, G_) if (sh.C == C_ && sh.G == G_) step_shape<T, C_, G_, true>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, pk);
+#define X(C_, G_) if (sh.C == C_ && sh.G == G_) step_shape<T, C_, G_, true>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic);
         ACAS2D_PACKED_SHAPES(X)
 #undef X
     } else {
         switch (sh.G) {
-            case 1:  step_shape<T, 1, 1, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, pk); break;
-            case 4:  step_shape<T, 1, 4, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, pk); break;
-            case 16: step_shape<T, 1, 16, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, pk); break;
-            default: step_shape<T, 1, 64, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, pk); break;
+            case 1:  step_shape<T, 1, 1, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 4:  step_shape<T, 1, 4, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 16: step_shape<T, 1, 16, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            default: step_shape<T, 1, 64, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
         }
     }
     return check_launch("acas2d_step launch");
@@ -302,7 +268,6 @@ int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* 
                  hipStream_t stream) {
     if (!cfg) { set_error("acas2d_reset: NULL cfg"); return ACAS2D_EINVAL; }
     if (!state_complete(st)) { set_error("acas2d_reset: NULL state or a NULL state buffer"); return ACAS2D_EINVAL; }
-    if (do_init < 0 && !st->pool) return ACAS2D_OK;        // pool refresh without a pool: nothing to do
     if (n_traffic < 1) { set_error("acas2d_reset: n_traffic = %d", n_traffic); return ACAS2D_EINVAL; }
     if (n_envs < 0 || env_offset < 0) { set_error("acas2d_reset: negative n_envs / env_offset"); return ACAS2D_EINVAL; }
     if (n_envs == 0) return ACAS2D_OK;
@@ -314,30 +279,20 @@ int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* 
     const ResetParams rp = make_reset_params<double>(*cfg);
     const State<T> s = make_state<T>(*st);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    const PoolArg pk = make_pool<T>(*cfg, *st, sh, seed, env_offset, n_envs, n_traffic);
-    if (pk.base && ((uintptr_t)pk.base & 15u)) { set_error("acas2d_reset: the pool must be 16-byte aligned"); return ACAS2D_EINVAL; }
-    if (do_init < 0) { if (!pk.base) return ACAS2D_OK; obs = nullptr; }
+    if (do_init < 0) { set_error("acas2d_reset: do_init = %d", do_init); return ACAS2D_EINVAL; }
     if (sh.packed) {
-#define X(C_, G_) if (sh.C == C_ && sh.G == G_) reset_shape<T, C_, G_, true>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic, pk);
+#define X(C_, G_) if (sh.C == C_ && sh.G == G_) reset_shape<T, C_, G_, true>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic);
         ACAS2D_PACKED_SHAPES(X)
 #undef X
     } else {
         switch (sh.G) {
-            case 1:  reset_shape<T, 1, 1, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic, pk); break;
-            case 4:  reset_shape<T, 1, 4, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic, pk); break;
-            case 16: reset_shape<T, 1, 16, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic, pk); break;
-            default: reset_shape<T, 1, 64, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic, pk); break;
+            case 1:  reset_shape<T, 1, 1, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 4:  reset_shape<T, 1, 4, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 16: reset_shape<T, 1, 16, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            default: reset_shape<T, 1, 64, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
         }
     }
     return check_launch("acas2d_reset launch");
-}
-
-template <typename T>
-int64_t pool_bytes(int64_t n_envs, int32_t n_traffic) {
-    Shape sh;
-    if (n_envs <= 0 || n_traffic < 1 || resolve_shape<T>(n_traffic, &sh)) return 0;
-    if (!pool_shape_ok(sh.C, sh.G, sh.packed, (int)sizeof(T))) return 0;
-    return pool_bytes_for<T>(n_envs, n_traffic);
 }
 
 template <typename T>

@@ -8,7 +8,7 @@ from .config import CConfig
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libacas2d_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 AUTO_RESET = 1
 
@@ -16,7 +16,7 @@ AUTO_RESET = 1
 class CState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi",
-        "trf_v", "steps", "total_reward", "status", "episode", "pool", "trace")]
+        "trf_v", "steps", "total_reward", "status", "episode", "hint", "trace", "stats")]
 
 
 class CStepIO(C.Structure):
@@ -30,8 +30,7 @@ class CPolicy(C.Structure):
                [("hidden", C.c_int32), ("_pad", C.c_int32)]
 
 
-EXPORTS = ("acas2d_abi_version", "acas2d_config_size", "acas2d_state_size", "acas2d_pool_bytes",
-           "acas2d_last_error", "acas2d_step_f32",
+EXPORTS = ("acas2d_abi_version", "acas2d_config_size", "acas2d_state_size", "acas2d_last_error", "acas2d_step_f32",
            "acas2d_step_f64", "acas2d_rollout_f32", "acas2d_rollout_f64", "acas2d_rollout_policy_f32",
            "acas2d_rollout_policy_f64", "acas2d_reset_f32", "acas2d_reset_f64", "acas2d_launch_geometry")
 
@@ -74,8 +73,6 @@ def lib():
     L.acas2d_abi_version.restype = C.c_int
     L.acas2d_config_size.restype = C.c_size_t
     L.acas2d_state_size.restype = C.c_size_t
-    L.acas2d_pool_bytes.restype = C.c_size_t
-    L.acas2d_pool_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     L.acas2d_last_error.restype = C.c_char_p
     for name in ("acas2d_step_f32", "acas2d_step_f64"):
         f = getattr(L, name)
@@ -114,11 +111,6 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError("acas2d: error %d: %s" % (rc, lib().acas2d_last_error().decode()))
-
-
-def pool_bytes(n_envs, n_traffic, elem_size=4):
-    """Size of the episode pool (Acas2dState.pool) for this configuration; 0 = no pooled step kernel."""
-    return int(lib().acas2d_pool_bytes(n_envs, n_traffic, elem_size))
 
 
 def launch_geometry(n_envs, n_traffic, elem_size=4):

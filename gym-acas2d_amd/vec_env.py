@@ -93,16 +93,19 @@ class ACAS2DVecEnv:
     record_trace   (auto_reset=False only) keep `trace` [E, 16]: the per-step record row behind
                    testing_main.py:114-138's CSV columns (include/acas2d.h, Acas2dState.trace;
                    TRACE_COLUMNS below), rewritten by every reset*() / set_state(observe=True) / step()
-    episode_pool   keep the next two episodes of every env pre-generated in HBM (include/acas2d.h,
-                   Acas2dState.pool) so that re-initialising a finished env does not sit at the end of
-                   the step launch; a cache -- results are bit-identical with and without it
+    speculative_reset  keep `hint` [E] (include/acas2d.h, Acas2dState.hint): every step flags the envs that
+                   may finish at the next one, and the next step generates their next episodes while its
+                   loads are in flight, so that re-initialising a finished env does not sit at the end
+                   of the launch; results are bit-identical with and without it
+    count_resets   (tests / diagnostics) keep `reset_stats`: finished envs re-initialised from a
+                   speculatively generated episode / inside the step
     """
 
     metadata = {"render.modes": []}
 
     def __init__(self, num_envs, n_traffic=1, device="cuda", dtype=torch.float32, seed=13,
-                 env_offset=0, auto_reset=True, keep_terminal_obs=True, config=None, episode_pool=True,
-                 record_trace=False):
+                 env_offset=0, auto_reset=True, keep_terminal_obs=True, config=None, speculative_reset=True,
+                 record_trace=False, count_resets=False):
         if config is None:
             config = ACAS2DConfig(n_traffic=n_traffic)
         self.config = config
@@ -134,8 +137,9 @@ class ACAS2DVecEnv:
         self.total_reward = z(E)
         self.status = z(E, dt=torch.uint8)
         self.episode = z(E, dt=torch.int32)            # bit pattern of the u32 counter
-        nbytes = native.pool_bytes(E, N, 4 if dtype == torch.float32 else 8) if (episode_pool and auto_reset) else 0
-        self.pool = torch.zeros(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+        # 1 = "may finish": the safe value wherever nothing has worked the flag out yet
+        self.hint = torch.ones(E, dtype=torch.uint8, device=dev) if (speculative_reset and auto_reset) else None
+        self.stats = z(4, dt=torch.int32) if count_resets else None
         if record_trace and auto_reset:
             raise ValueError("record_trace needs auto_reset=False (the reference's single-env semantics)")
         self.trace = z(E, len(TRACE_COLUMNS) + 3) if record_trace else None
@@ -173,26 +177,23 @@ class ACAS2DVecEnv:
             self.env_offset, self.num_envs, self.n_traffic, self._stream()))
 
     # ---- gym / VecEnv surface -------------------------------------------------------------------
-    def refresh_pool(self):
-        """Rebuild the episode pool from the current episode counters (after anything but step() /
-        reset*() changed them: a fused rollout, a restored checkpoint, another seed)."""
-        if self.pool is not None:
-            with torch.cuda.device(self.device):
-                self._launch_reset(None, do_init=-1, with_obs=False)
+    def invalidate_hints(self):
+        """After anything but step() / reset*() / set_state() changed the state (a fused rollout, a restored
+        checkpoint): every env counts as "may finish" until the next step has worked its flag out again."""
+        if self.hint is not None:
+            self.hint.fill_(1)
 
-    def pool_counters(self):
-        """Diagnostics: {"pool": resets served from the episode pool, "in_step": resets generated inside
-        the step although a pool is attached (stale or unfetched slot), "refilled": slots refilled by the
-        helper waves} since construction; None without a pool."""
-        if self.pool is None:
+    def reset_stats(self):
+        """Diagnostics (count_resets=True): {"speculated": finished envs re-initialised from an episode generated
+        in the load shadow, "in_step": finished envs re-initialised inside the step} since construction."""
+        if self.stats is None:
             return None
-        c = self.pool[:12].view(torch.int32).cpu().tolist()
-        return {"pool": c[0], "in_step": c[1], "refilled": c[2]}
+        c = self.stats.cpu().tolist()
+        return {"speculated": c[0], "in_step": c[1]}
 
     def seed(self, seed=None):
-        if seed is not None and int(seed) != self.seed_value:
+        if seed is not None:
             self.seed_value = int(seed)
-            self.refresh_pool()
         return [self.seed_value + i for i in range(min(self.num_envs, 16))]
 
     def reset(self):
@@ -318,7 +319,7 @@ class ACAS2DVecEnv:
             native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), T, self.seed_value,
                             self.env_offset, E, self.n_traffic, self._stream()))
             self._obs.copy_(out["obs"][T - 1])        # outputs["obs"] stays "the latest observation"
-            self.refresh_pool()                       # the rollout kernels do not maintain the episode pool
+            self.invalidate_hints()                   # the rollout kernels do not maintain the hints
         out["_actions"] = a          # keep the (possibly re-laid-out) input alive until the launch ran
         return out
 
@@ -363,7 +364,7 @@ class ACAS2DVecEnv:
             native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), C.byref(pol), ptr(self._obs),
                             T, self.seed_value, self.env_offset, E, self.n_traffic, self._stream()))
             self._obs.copy_(out["obs"][T - 1])        # the observation the NEXT action would be taken on
-            self.refresh_pool()                       # the rollout kernels do not maintain the episode pool
+            self.invalidate_hints()                   # the rollout kernels do not maintain the hints
         out["_weights"] = keep       # keep the transposed copies alive until the launch ran
         return out
 
@@ -408,7 +409,7 @@ class ACAS2DVecEnv:
     def load_state_dict(self, sd):
         for n, v in sd.items():
             getattr(self, n).copy_(v)
-        self.refresh_pool()
+        self.invalidate_hints()
 
     def algorithmic_bytes_per_step(self):
         s = 4 if self.dtype == torch.float32 else 8

@@ -75,7 +75,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol(g):
     for name in declared:
         assert hasattr(L, name), name
     assert set(g.native.EXPORTS) == declared
-    assert L.acas2d_abi_version() == g.native.ABI_VERSION == 3 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
+    assert L.acas2d_abi_version() == g.native.ABI_VERSION == 4 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
     assert int(re.search(r"#define ACAS2D_ABI_VERSION (\d+)", header).group(1)) == g.native.ABI_VERSION
 
 
@@ -88,7 +88,7 @@ def test_c_abi_argument_validation_needs_no_gpu(g):
     assert L.acas2d_step_f64(C.byref(cfg), C.byref(st), C.byref(io), 0, 0, 0, 4, 1, None) == -22
     assert b"state" in L.acas2d_last_error()
     dummy = (C.c_double * 64)()
-    full = g.native.CState(*([C.addressof(dummy)] * 14))        # pool stays NULL
+    full = g.native.CState(*([C.addressof(dummy)] * 14))        # hint, trace, stats stay NULL
     assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), C.byref(io), 0, 0, 0, 4, 1, None) == -22
     assert b"required" in L.acas2d_last_error()
     io_ok = g.native.CStepIO(*([C.addressof(dummy)] * 5 + [None] * 3))
@@ -107,12 +107,7 @@ def test_c_abi_argument_validation_needs_no_gpu(g):
     assert g.native.launch_geometry(4096, 3)["lanes_per_env"] == 1
     assert g.native.launch_geometry(10, 1)["lanes_per_env"] == 1
     assert g.native.launch_geometry(65536, 64)["lanes_per_env"] == 16
-    # the episode pool: sized by the library, only for shapes that have a pooled step kernel
     assert L.acas2d_state_size() == C.sizeof(g.native.CState)
-    assert g.native.pool_bytes(65536, 8) > 65536 * 2 * (4 * 8 + 1 + 29) * 4 and g.native.pool_bytes(65536, 8) % 16 == 0
-    assert g.native.pool_bytes(65536, 8, 8) == 0                                   # float32 step kernels only
-    assert g.native.pool_bytes(65536, 64) == 0 and g.native.pool_bytes(4096, 200) == 0 and g.native.pool_bytes(0, 8) == 0
-    assert g.native.pool_bytes(1, 3) == g.native.pool_bytes(256, 3) < g.native.pool_bytes(257, 3)   # 256-env windows
     geo = g.native.launch_geometry(7, 200)                                          # generic walk
     assert geo["lanes_per_env"] == 64 and geo["traffic_per_lane"] == -1
     with pytest.raises(RuntimeError, match="LDS"):

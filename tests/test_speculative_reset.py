@@ -1,16 +1,15 @@
-"""GPU tests (-m gpu) of the episode pool (include/acas2d.h, Acas2dState.pool): the next two episodes of
-every env pre-generated in HBM, so that ACAS2DGame.__init__ + the first observe() of a finished env
-(game.py:80-116, environment.py:44-48) are not computed at the end of the step launch.  The pool is a
-CACHE of the reset distribution: every result must be bit-identical with and without it, in every
-situation that can leave a slot stale, and in steady state (almost) every reset must be served from it."""
+"""GPU tests (-m gpu) of the speculative reset (include/acas2d.h, Acas2dState.hint): every step flags the envs
+that may finish at the next one, and the next step generates their next episodes -- ACAS2DGame.__init__ + the
+first observe() (game.py:80-116, environment.py:44-48) -- while its loads are in flight instead of at the end
+of the launch.  The flags only decide which path re-initialises a finished env: every result must be
+bit-identical with and without them, in every situation that can leave them stale, and in steady state
+(almost) every reset must be served from a speculated episode."""
 import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-
-os.environ["ACAS2D_POOL_STATS"] = "1"        # event counters in the pool header (off by default: atomics)
 
 torch = pytest.importorskip("torch")
 
@@ -40,16 +39,18 @@ def _same(a, b, what):
 
 
 def _pair(g, E, N, dtype, seed=21, config=None):
-    a = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=seed, config=config, episode_pool=True)
-    b = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=seed, config=config, episode_pool=False)
-    assert a.pool is not None and b.pool is None
+    a = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=seed, config=config, count_resets=True)
+    b = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=seed, config=config, speculative_reset=False)
+    assert a.hint is not None and b.hint is None
     return a, b
 
 
 @pytest.mark.parametrize("dtype_name,N,E,T", (("float32", 8, 4096 + 37, 400), ("float32", 3, 5000, 300),
                                               ("float32", 1, 3000, 900), ("float32", 16, 1024, 120),
-                                              ("float32", 4, 2048, 200), ("float32", 2, 2000, 300)))
-def test_pool_is_a_pure_cache(g, dtype_name, N, E, T):
+                                              ("float32", 4, 2048, 200), ("float32", 2, 2000, 300),
+                                              ("float64", 8, 2048 + 3, 300), ("float64", 3, 1000, 200),
+                                              ("float64", 1, 1500, 800)))
+def test_the_flags_only_choose_the_path(g, dtype_name, N, E, T):
     dtype = getattr(torch, dtype_name)
     a, b = _pair(g, E, N, dtype)
     _same([a.reset().clone()], [b.reset().clone()], "reset")
@@ -61,22 +62,21 @@ def test_pool_is_a_pure_cache(g, dtype_name, N, E, T):
         _same(sa, sb, "step %d" % t)
         finished += int(sa[2].sum())
         if t == 4:
-            c_early, f_early = a.pool_counters(), finished
-    c = a.pool_counters()
-    assert finished > 20 and c["pool"] + c["in_step"] == finished, (finished, c)
-    # A reset is generated inside the step only when more envs of one wave may finish at once than the wave
-    # prefetches first observations for (kPoolRows = 4): the burst right after reset() (a fifth of the fresh
-    # episodes start inside a collision disc and end at step 1, game.py:109-110) and hardly ever after it.
-    late, late_pool = finished - f_early, c["pool"] - c_early["pool"]
-    assert late > 20 and late_pool >= 0.99 * late, (finished, c_early, c)
-    assert c["refilled"] >= c["pool"] + c["in_step"] - E      # every reset asked for one refill (the last step's are pending)
+            c_early, f_early = a.reset_stats(), finished
+    c = a.reset_stats()
+    assert finished > 20 and c["speculated"] + c["in_step"] == finished, (finished, c)
+    # A reset is generated at the end of the step only when more envs of one wave are flagged at once than the
+    # wave has reset slots: the burst right after reset() (a fifth of the fresh episodes start inside a
+    # collision disc and end at step 1, game.py:109-110) and hardly ever after it.
+    late, late_spec = finished - f_early, c["speculated"] - c_early["speculated"]
+    assert late > 20 and late_spec >= 0.98 * late, (finished, c_early, c)
 
 
-def test_pool_with_bursts_of_simultaneous_and_back_to_back_finishes(g):
+def test_bursts_of_simultaneous_and_back_to_back_finishes(g):
     """max_steps = 3: every env times out at the same step, every third step -- whole waves finish at once
-    (far more than the 4 first observations a wave prefetches: pool commits and in-step generation side by
+    (far more than a wave has reset slots: commits of speculated episodes and in-step generation side by
     side), and an env whose fresh episode starts inside a collision disc finishes in consecutive steps."""
-    for dtype, N in ((torch.float32, 8), (torch.float32, 3), (torch.float32, 2)):
+    for dtype, N in ((torch.float32, 8), (torch.float32, 3), (torch.float32, 2), (torch.float64, 8)):
         cfg = g.ACAS2DConfig(n_traffic=N, max_steps=3)
         E = 2048 + 5
         a, b = _pair(g, E, N, dtype, seed=3, config=cfg)
@@ -88,14 +88,14 @@ def test_pool_with_bursts_of_simultaneous_and_back_to_back_finishes(g):
             sa, sb = _snapshot(a, a.step(act)), _snapshot(b, b.step(act))
             _same(sa, sb, ("burst", N, t))
             total += int(sa[2].sum())
-        c = a.pool_counters()
-        assert total > 10 * E and c["pool"] + c["in_step"] == total and c["pool"] > 0 and c["in_step"] > 0, (total, c)
+        c = a.reset_stats()
+        assert total > 10 * E and c["speculated"] + c["in_step"] == total and c["speculated"] > 0 and c["in_step"] > 0, (total, c)
 
 
-def test_pool_survives_everything_that_can_leave_it_stale(g):
-    """reset_masked(), set_state(), a fused rollout (which does not maintain the pool), a checkpoint
-    restore, another seed, and a caller that edits episode[] behind the engine's back: same bits as the
-    env without a pool after each of them."""
+def test_results_survive_everything_that_can_leave_the_flags_stale(g):
+    """reset_masked(), set_state(), a fused rollout (which does not maintain the flags), a checkpoint
+    restore, another seed, a caller that edits episode[] or the positions behind the engine's back, flags
+    cleared by hand: same bits as the env without the flags after each of them."""
     dtype, N, E = torch.float32, 8, 3072
     a, b = _pair(g, E, N, dtype, seed=5)
     a.reset(); b.reset()
@@ -121,28 +121,37 @@ def test_pool_survives_everything_that_can_leave_it_stale(g):
     steps(60, "after restore")
     a.seed(77); b.seed(77)
     steps(60, "after seed")
-    before = a.pool_counters()
-    a.episode.add_(5); b.episode.add_(5)                      # behind the engine's back: every slot is stale now
+    a.episode.add_(5); b.episode.add_(5)                      # behind the engine's back
     steps(80, "after editing episode[]")
-    after = a.pool_counters()
-    assert after["in_step"] > before["in_step"]              # stale slots were ignored, not used
+    before = a.reset_stats()
+    a.hint.zero_()                                            # "nobody can finish": every finish of the next step is unflagged
+    steps(1, "flags cleared by hand")
+    after = a.reset_stats()
+    assert after["in_step"] > before["in_step"] and after["speculated"] == before["speculated"]
+    steps(40, "after the flags were cleared")
+    a.trf_x.copy_(a.own_x[:, None] + 50.0); b.trf_x.copy_(b.own_x[:, None] + 50.0)      # everybody collides, nobody flagged
+    a.trf_y.copy_(a.own_y[:, None]); b.trf_y.copy_(b.own_y[:, None])
+    a.hint.zero_()
+    steps(30, "positions edited behind the engine's back")
     own = np.tile([[48.0, 500.0, 0.0, 200.0]], (E, 1))
     trf = np.tile([[[600.0, 400.0, 180.0, 200.0]] * N], (E, 1, 1))
     a.set_state(own, trf); b.set_state(own, trf)
     steps(300, "after set_state: head-on, everybody collides in the same steps")
 
 
-def test_pool_at_the_headline_size_serves_every_reset(g):
+def test_at_the_headline_size_every_reset_is_speculated(g):
     E, N = 65536, 8
-    a = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, seed=13)
+    a = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, seed=13, count_resets=True)
     a.reset()
     gen = torch.Generator(device="cuda:0").manual_seed(2)
     acts = torch.rand(64, E, generator=gen, device="cuda:0") * 2 - 1
     for t in range(400):
         a.step_from(acts[t % 64])
-    c0 = a.pool_counters()
+    c0 = a.reset_stats()
     for t in range(400):
         a.step_from(acts[t % 64])
-    c1 = a.pool_counters()
-    served, slow = c1["pool"] - c0["pool"], c1["in_step"] - c0["in_step"]
-    assert served > 50000 and slow <= 0.001 * served, (c0, c1)
+    c1 = a.reset_stats()
+    served, slow = c1["speculated"] - c0["speculated"], c1["in_step"] - c0["in_step"]
+    flagged = float(a.hint.float().mean())
+    print("speculated %d, in-step %d, flagged envs %.2f %%" % (served, slow, 100 * flagged))
+    assert served > 50000 and slow <= 0.002 * served and flagged < 0.03, (c0, c1, flagged)
