@@ -74,10 +74,6 @@ def parse(argv=None):
     ap.add_argument("--no-collisions", action="store_true",
                     help="diagnostic (SURVEY.md 8d, C4): collision distance 0, so episodes end at the goal / by "
                          "timeout only and resets are rare -- isolates the step itself at large N_TRAFFIC")
-    ap.add_argument("--no-spec", action="store_true",
-                    help="A/B: without the speculative reset (every finished env is re-initialised at the end of its step)")
-    ap.add_argument("--reset-stats", action="store_true",
-                    help="diagnostic: count speculated / in-step resets (atomics on the reset paths)")
     ap.add_argument("--no-terminations", action="store_true",
                     help="diagnostic: no collisions, no goal, no timeout -- nothing ever finishes (the reset-free floor)")
     return ap.parse_args(argv)
@@ -237,8 +233,7 @@ class StepRunner:
 
 def make_env(g, E, N, dtype, dev, rank, args):
     env = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13, env_offset=rank * E,
-                         auto_reset=not args.no_auto_reset, speculative_reset=not args.no_spec,
-                         count_resets=args.reset_stats)
+                         auto_reset=not args.no_auto_reset)
     if args.no_collisions or args.no_terminations:
         env._ccfg.collision_dist = 0.0
     if args.no_terminations:
@@ -423,8 +418,7 @@ def main():
                              "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"],
                              "grid_blocks": geo["grid_blocks"],
                              "parallelism": "env-index shards x%d, no collective on the step path" % world,
-                             "episodes_finished": int(episodes),
-                             "speculative_reset": not args.no_spec, "reset_stats": env.reset_stats()}
+                             "episodes_finished": int(episodes)}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(E, N, args.dtype),
                                "kernel": "acas2d::step_kernel<%s, C=%d, G=%d>" % ("float" if s == 4 else "double",

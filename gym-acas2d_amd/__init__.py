@@ -8,7 +8,7 @@ root is the import shim).
 from .config import ACAS2DConfig, OUTCOME_NAMES                      # noqa: F401
 from .sharding import shard_range                                    # noqa: F401
 from .spaces import Box                                              # noqa: F401
-from . import native, records, reset_parity, sharding                # noqa: F401
+from . import native, records, render, reset_parity, sharding        # noqa: F401
 from .vec_env import ACAS2DVecEnv, LazyInfos                         # noqa: F401
 from .env import ACAS2DEnv, GameView, register_with_gym              # noqa: F401
 from .policy import SB3ActorPolicy, load_sb3_policy, evaluate_policy, evaluate_policy_fused  # noqa: F401

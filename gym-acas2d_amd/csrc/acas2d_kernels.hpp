@@ -110,8 +110,6 @@ struct State {
     uint8_t* status;
     uint32_t* episode;
     T* trace;                 // optional [E][kTraceWidth] (latching kernels and reset only), see write_trace()
-    uint8_t* hint;            // optional [E]: may this env finish at the next step (see "speculative reset")
-    uint32_t* stats;          // optional [4]: diagnostic event counters (tests), see Acas2dState.stats
 };
 
 template <typename T>
@@ -131,7 +129,7 @@ __device__ __forceinline__ State<T> rebase(const State<T>& s, int64_t e0, int N)
     return State<T>{s.own_x + e0, s.own_y + e0, s.own_psi + e0, s.own_v + e0, s.goal_x + e0, s.goal_y + e0,
                     s.trf_x + e0 * N, s.trf_y + e0 * N, s.trf_psi + e0 * N, s.trf_v + e0 * N,
                     s.steps + e0, s.total_reward + e0, s.status + e0, s.episode + e0,
-                    s.trace ? s.trace + e0 * kTraceWidth : nullptr, s.hint ? s.hint + e0 : nullptr, s.stats};
+                    s.trace ? s.trace + e0 * kTraceWidth : nullptr};
 }
 template <typename T>
 __device__ __forceinline__ StepIO<T> rebase(const StepIO<T>& io, int64_t e0, int D) {
@@ -409,7 +407,7 @@ __device__ __forceinline__ int64_t remap_block(uint32_t trailing = 0u) {
 // ---- Philox4x32-10 counter-based reset RNG ---------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
 #ifndef ACAS2D_PHILOX_ROUNDS
-#define ACAS2D_PHILOX_ROUNDS 10          // diagnostic builds only: the reset chain's latency knob
+#define ACAS2D_PHILOX_ROUNDS 10          // anything else: diagnostic builds only (the reset chain's latency knob)
 #endif
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -473,21 +471,7 @@ template <typename T>
 struct Seen {
     T d_goal, h_goal, d_dev, v_closing0, d_cpa0;
     int collided;
-    int near;                 // HINT only: some traffic aircraft can be within the collision distance after the NEXT step
 };
-
-// ---- "may this env finish at the next step" (Acas2dState.hint) ---------------------------------------
-// Conservative by construction: in one step the player moves by exactly v dt and an aircraft by v_k dt
-// (aircraft.py:24-25), so the distance between them shrinks by at most (v + v_k) dt and the distance to the
-// goal by at most v dt; the slack (1e-4 relative on the motion, 0.01 px absolute) covers every rounding on the
-// way in both element types.  NaN compares false here exactly as in game.py:185-192.
-template <typename T> __device__ __forceinline__ T hint_dt(const Params<T>& p) { return p.dt * T(1.0001); }
-template <typename T> __device__ __forceinline__ T hint_collision_base(const Params<T>& p, T own_v) {
-    return m_fma(own_v, hint_dt(p), p.collision_dist + T(0.01));
-}
-template <typename T> __device__ __forceinline__ bool may_reach_goal(const Params<T>& p, T own_v, T d_goal) {
-    return d_goal < m_fma(own_v, hint_dt(p), p.goal_radius + T(0.01));
-}
 
 // ZERO_ACTION (a freshly reset episode: a_lat = 0, heading in [0, 360)): the one-step-ahead heading
 // of closing_speed() is the heading itself, bit for bit, so its sin / cos are not computed twice.
@@ -710,7 +694,7 @@ __device__ __forceinline__ T minimum_separation(const State<T>& s, const Own<T>&
 // loads / stores aircraft by aircraft.
 // `after_own(c)` runs between the player side and the traffic side (the record rows' minimum separation).
 struct NoHook { template <typename X> __device__ __forceinline__ void operator()(const X&) const {} };
-template <typename T, int C, int G, bool PACKED, bool FAST, bool HINT = false, typename Hook = NoHook>
+template <typename T, int C, int G, bool PACKED, bool FAST, typename Hook = NoHook>
 __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
                                            int e, int j, int N, int32_t steps, bool move,
                                            Traffic<T, C>& tr, T* __restrict__ row, bool store_traffic = true,
@@ -724,7 +708,6 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
     r.d_goal = c.d_goal; r.h_goal = c.h_goal; r.d_dev = c.d_dev;
     int coll = 0;
     T vc0 = T(0), dc0 = T(0);
-    const T near_base = HINT ? hint_collision_base(p, c.v) : T(0), near_dt = HINT ? hint_dt(p) : T(0);
     if constexpr (PACKED) {
         using V = Vec<T, C>;
         const int i0 = e * N + j * C;
@@ -790,10 +773,6 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
                 traffic_observe2(p, c, F2{tr.x.v[k], tr.x.v[k + 1]}, F2{tr.y.v[k], tr.y.v[k + 1]},
                                  F2{tr.v.v[k], tr.v.v[k + 1]}, F2{st[k], st[k + 1]}, F2{ct[k], ct[k + 1]}, d, dca, vc);
                 coll |= ((d.x < p.collision_dist) | (d.y < p.collision_dist)) ? 1 : 0;   // game.py:185-189
-                if constexpr (HINT) {
-                    const F2 thr = m_fma(F2{tr.v.v[k], tr.v.v[k + 1]}, F2{near_dt, near_dt}, F2{near_base, near_base});
-                    coll |= ((d.x < thr.x) | (d.y < thr.y)) ? 2 : 0;
-                }
                 const F2 dn = d * p.inv_d_sep_max, cn = dca * p.inv_d_cpa_max, vn = vc * p.inv_v_closing_max;
                 T* q = row + 5 + 3 * (j * C + k);                                 // game.py:205-210
                 q[0] = dn.x; q[1] = cn.x; q[2] = vn.x; q[3] = dn.y; q[4] = cn.y; q[5] = vn.y;
@@ -805,7 +784,6 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
                 T d, dca, vc;
                 traffic_observe<T, FAST>(p, c, tr.x.v[k], tr.y.v[k], tr.v.v[k], st[k], ct[k], d, dca, vc);
                 coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
-                if constexpr (HINT) coll |= (d < m_fma(tr.v.v[k], near_dt, near_base)) ? 2 : 0;
                 put_traffic_obs<T, FAST>(p, row + 5 + 3 * (j * C + k), d, dca, vc);
                 if (k == 0) { vc0 = vc; dc0 = dca; }
             }
@@ -823,14 +801,11 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
                 if (tpsi != psi_in) s.trf_psi[i] = tpsi;
             }
             coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
-            if constexpr (HINT) coll |= (d < m_fma(tv, near_dt, near_base)) ? 2 : 0;
             put_traffic_obs<T, FAST>(p, row + 5 + 3 * n, d, dca, vc);
             if (n == 0) { vc0 = vc; dc0 = dca; }
         }
     }
-    coll = group_or<G>(coll);
-    r.collided = coll & 1;
-    r.near = coll & 2;
+    r.collided = group_or<G>(coll);
     r.v_closing0 = group_bcast0<G>(vc0);                  // evaluate() reads traffic[0] only,
     r.d_cpa0 = group_bcast0<G>(dc0);                      // game.py:254-255
     if (j == 0) put_own_obs<T, FAST>(p, row, steps, o.psi, c);
@@ -1027,13 +1002,11 @@ template <int NS> struct ResetSlots {
     static constexpr int SLOTS = 64 / STRIDE;
 };
 // One reset slot in the wave's LDS, in values of T: the new traffic block x[N] y[N] psi[N] v[N] (each 16-byte
-// aligned for the packed shapes' vector reads), the player's heading, the new episode's hint, and -- written
-// by the speculative generation only -- the new episode's first observation.  Slots start 16-byte aligned.
+// aligned for the packed shapes' vector reads) and the player's heading.  Slots start 16-byte aligned.
 template <typename T, int NS> struct SlotLayout {
     static constexpr int W = 16 / (int)sizeof(T);
-    static constexpr int OWN_PSI = 4 * NS, HINT = 4 * NS + 1;
-    static constexpr int OBS = (4 * NS + 2 + W - 1) / W * W;
-    static constexpr int STRIDE = (OBS + 5 + 3 * NS + W - 1) / W * W;
+    static constexpr int OWN_PSI = 4 * NS;
+    static constexpr int STRIDE = (4 * NS + 1 + W - 1) / W * W;
 };
 
 // Resets the envs named by the lowest min(SLOTS, popcount(dm)) bits of `dm` (bit = lane of the env's
@@ -1104,10 +1077,6 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
         psi_own = have ? scr[4 * N] : T(0);
     }
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-#ifdef ACAS2D_EXP_SKIP_FIRST_OBS
-    if (mine) { if (ent >= 1) { row[5 + 3 * (ent - 1)] = tx; row[6 + 3 * (ent - 1)] = ty; row[7 + 3 * (ent - 1)] = tv; } else { row[0] = psi_own; } }
-    return taken;
-#endif
     const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
     // environment.py:44-48: the new episodes' first observations (steps becomes 1)
     if (mine) {
@@ -1118,83 +1087,6 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
         } else {
             put_own_obs<T, FAST>(p, row, 1, o.psi, c);
         }
-    }
-    return taken;
-}
-
-// ---- speculative reset (Acas2dState.hint) ---------------------------------------------------------------
-// Re-initialising a finished env is ACAS2DGame.__init__ (game.py:80-116: one RNG block per aircraft) plus the
-// new episode's first observe() (environment.py:44-48): ~600 dependent instructions at the very END of the
-// launch, on the wave every other wave then waits for (the launch ends with its slowest wave; measured at
-// 65 536 x 8: 5.9 us per launch against 4.7 us when nothing ever finishes -- RNG + first observation 0.6 us,
-// moving the new state into place 0.5 us).  Which envs CAN finish at step t + 1 is known at step t: the player
-// and the traffic move by exactly v dt per step, so an env whose aircraft are all further than the collision
-// distance + (v + v_k) dt apart, whose goal is further than the goal radius + v dt away and whose step counter
-// is below the limit cannot finish (hint helpers above).  Every step leaves that flag in hint[e] (about 1 % of
-// the envs at the default configuration); the next step loads hint and episode FIRST and, while the rest of its
-// loads are in flight and the vector ALUs would idle, generates the next episode of every flagged env -- up to
-// SLOTS of them side by side, lane `ent` of a slot = entity `ent`, the same per-lane functions as
-// wave_reset_slots(), hence the same bits -- into the wave's reset slots in LDS: state, first observation,
-// hint.  A finished env whose slot is there is re-initialised by the commit in step_kernel (LDS reads, the row
-// swap, register selects); anything else -- hint not maintained by the caller's path, more flagged envs than
-// slots -- takes wave_reset_slots() as before.  Results never depend on hint[]: it only decides which path
-// produces them.
-template <typename T, bool FAST, int NS, int G, typename R>
-__device__ __forceinline__ unsigned long long spec_generate(const Params<T>& p, const ResetParamsT<R>& rp, uint32_t k0,
-                                                            uint32_t k1, uint64_t gid_wave, unsigned long long cm, int lane,
-                                                            uint32_t episode_lane, T* __restrict__ slots, int& src_out) {
-    using RS = ResetSlots<NS>;
-    using SL = SlotLayout<T, NS>;
-    constexpr int N = NS;
-    const int slot = lane / RS::STRIDE, ent = lane % RS::STRIDE;
-    unsigned long long taken = 0;
-    int src = -1;                                         // the lane of my slot's env's group leader
-    uint32_t episode_prev = 0;
-    for (int k = 0; k < RS::SLOTS && cm != 0; ++k) {       // slot k <- the k-th flagged env; wave-uniform
-        const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
-        cm &= cm - 1;
-        taken |= 1ull << b;
-        const uint32_t ep_b = (uint32_t)lane_value((int)episode_lane, b);
-        if (slot == k) { src = b; episode_prev = ep_b; }
-    }
-    src_out = src;
-    const bool have = src >= 0;
-    const int e = (src & 63) / G;                         // my slot's env (in the wave)
-    T* sk = slots + slot * SL::STRIDE;
-    const uint64_t gid = gid_wave + (uint64_t)e;
-    T tx = T(0), ty = T(0), tpsi = T(0), tv = T(0);
-    const bool mine = have && ent <= N;
-#ifdef ACAS2D_EXP_GEN_FAKE
-    if (mine) {     // timing experiment: a plausible episode at no cost (what an off-path generator would leave behind)
-        tx = T(800) + T(37) * ent; ty = T(100) + T(90) * ent; tpsi = T(40) * ent; tv = T(200);
-        if (ent >= 1) { const int n = ent - 1; sk[n] = tx; sk[N + n] = ty; sk[2 * N + n] = tpsi; sk[3 * N + n] = tv;
-                        sk[SL::OBS + 5 + 3 * n] = T(0.1); sk[SL::OBS + 6 + 3 * n] = T(0.2); sk[SL::OBS + 7 + 3 * n] = T(0.3); }
-        else { sk[SL::OWN_PSI] = T(0); sk[SL::HINT] = T(0); sk[SL::OBS] = T(0.001); sk[SL::OBS + 1] = T(0); sk[SL::OBS + 2] = T(0); sk[SL::OBS + 3] = T(0.4); sk[SL::OBS + 4] = T(0); }
-    }
-    return taken;
-#endif
-    if (mine) reset_entity<T, R>(rp, k0, k1, (uint32_t)gid, (uint32_t)(gid >> 32), episode_prev + 1u, ent, tx, ty, tpsi, tv);
-    const T psi_own = __shfl(tpsi, lane & ~(RS::STRIDE - 1), 64);         // the slot's player heading
-    const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-    const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
-    bool near = false;
-    if (mine) {
-        if (ent >= 1) {
-            const int n = ent - 1;
-            sk[n] = tx; sk[N + n] = ty; sk[2 * N + n] = tpsi; sk[3 * N + n] = tv;
-            T d, dca, vc;
-            traffic_step<T, FAST>(p, c, false, tx, ty, tpsi, tv, d, dca, vc);      // environment.py:44-48: first observe()
-            put_traffic_obs<T, FAST>(p, sk + SL::OBS + 5 + 3 * n, d, dca, vc);
-            near = d < m_fma(tv, hint_dt(p), hint_collision_base(p, c.v));
-        } else {
-            sk[SL::OWN_PSI] = tpsi;
-            put_own_obs<T, FAST>(p, sk + SL::OBS, 1, o.psi, c);
-        }
-    }
-    const unsigned long long nb = __ballot(near);
-    if (mine && ent == 0) {
-        const unsigned long long mine_bits = (nb >> (slot * RS::STRIDE)) & ((RS::STRIDE == 64) ? ~0ull : ((1ull << RS::STRIDE) - 1ull));
-        sk[SL::HINT] = (mine_bits != 0 || may_reach_goal(p, c.v, c.d_goal) || 1 >= p.max_steps) ? T(1) : T(0);
     }
     return taken;
 }
@@ -1350,18 +1242,13 @@ __device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&
 // arithmetic is this same code, so rollout(T) == T x step() bit for bit.
 // With POLICY (rollout, one lane per env) the action of every step comes from policy_action() on the
 // previous observation instead of from actions[t][E], which becomes an output.
-// With SPEC (per-step launch, packed shape, auto-reset, Acas2dState.hint given) the next episode of every env
-// the previous step flagged is generated while the wave's loads are in flight (see "speculative reset").
-template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false,
-          bool SPEC = false>
+template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
                                                       int tile_elems, int n_steps, PolicyW pw) {
     static_assert(!ROLLOUT || (AUTO_RESET && PACKED), "rollout: auto-reset semantics, packed shapes");
     static_assert(!POLICY || (ROLLOUT && G == 1), "in-kernel policy: rollout mode, one lane per env");
-    static_assert(!SPEC || (PACKED && AUTO_RESET && !ROLLOUT && ResetSlots<C * G>::SLOTS >= 2),
-                  "speculative reset: per-step launch, packed shape, auto-reset, N + 1 <= 32");
     constexpr int NS = PACKED ? C * G : 0;         // packed shapes: n_traffic is a compile-time constant
     const int N = PACKED ? NS : N_arg;
     constexpr int EPW = 64 / G;                    // envs per wavefront
@@ -1373,7 +1260,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         asm volatile("" :: "s"(nb), "s"(n_envs), "s"(s_arg.own_x), "s"(s_arg.own_y), "s"(s_arg.own_psi), "s"(s_arg.own_v),
                      "s"(s_arg.goal_x), "s"(s_arg.goal_y), "s"(s_arg.trf_x), "s"(s_arg.trf_y), "s"(s_arg.trf_psi),
                      "s"(s_arg.trf_v), "s"(s_arg.steps), "s"(s_arg.total_reward), "s"(s_arg.episode), "s"(io_arg.actions),
-                     "s"(tile_elems), "s"(s_arg.hint));
+                     "s"(tile_elems));
     }
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
@@ -1397,7 +1284,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     ACAS2D_STAMP(1, wave, lane, false);
     int32_t steps = 0;
     uint32_t episode = 0;
-    uint32_t hint_in = 0;
     T total = T(0);
     Own<T> o{};
     Traffic<T, C> tr{};
@@ -1411,21 +1297,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     const bool run = PACKED ? true : active;
     const int el_l = (PACKED && !active) ? 0 : el;         // the env a lane LOADS
     if (run) {
-        // ---- every load of this lane up front: one memory round trip, all requests in flight.  SPEC: the
-        // hint and the episode counter first -- loads return in order, and the speculative generation below
-        // needs nothing else.  Then the player's scalars and the action, the traffic vectors (the bulk) last:
-        // the player-side arithmetic can start while the vectors are still landing
+        // ---- every load of this lane up front: one memory round trip, all requests in flight.  The
+        // player's scalars and the action first, the traffic vectors (the bulk) last: loads return in
+        // order, so the player-side arithmetic can start while the vectors are still landing
         // (s_waitcnt vmcnt(4), then vmcnt(0) before the first traffic instruction): 7.12 -> 7.0x us.
-        if constexpr (SPEC) {
-            hint_in = s.hint[el_l];
-            episode = s.episode[el_l];
-            asm volatile("" ::: "memory");                 // issued before everything below (a compiler fence only:
-                                                           // naming the values here would WAIT for them first)
-        }
         o = Own<T>{s.own_x[el_l], s.own_y[el_l], s.own_psi[el_l], s.own_v[el_l], T(0), s.goal_x[el_l], s.goal_y[el_l]};
         steps = s.steps[el_l];
         total = s.total_reward[el_l];
-        if constexpr (AUTO_RESET) { if constexpr (!SPEC) episode = s.episode[el_l]; }
+        if constexpr (AUTO_RESET) episode = s.episode[el_l];
         else frozen = s.status[el_l] != 0;                                 // game.py:243-245
         if constexpr (!POLICY) action_next = io0.actions[el_l];
         if constexpr (PACKED) tr = load_traffic<T, C>(s, el_l * N + j * C);
@@ -1445,23 +1324,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                      "s"(rp.tn_y_max), "s"(rp.speed_factor_min), "s"(rp.speed_factor_max), "s"(rp.airspeed),
                      "s"(k0), "s"(k1), "s"(io_arg.ep_steps));
     }
-    // ---- SPEC: the next episodes of the flagged envs, generated while the rest of the loads are in flight
-    unsigned long long spec_mask = 0;                      // envs with a generated slot (bit = group leader's lane)
-    int spec_src = -1;                                     // per lane: the group leader's lane of my slot's env
-    if constexpr (SPEC) {
-#ifdef ACAS2D_EXP_NO_EARLY
-        const unsigned long long cm = 0;
-#else
-        const unsigned long long cm = __ballot(active && hint_in != 0 && j == 0);
-#endif
-        if (cm != 0)                                       // wave-uniform: about one wave in five at 65 536 x 8
-#ifdef ACAS2D_EXP_GEN_EMPTY
-            spec_mask = 0;
-        else
-#endif
-            spec_mask = spec_generate<T, FAST, NS, G>(p, rp, k0, k1, (uint64_t)(env_offset + e_wave), cm, lane, episode,
-                                                      scratch, spec_src);
-    }
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
     const int T_steps = ROLLOUT ? n_steps : 1;
     if constexpr (POLICY) {
@@ -1478,7 +1340,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                            io0.ep_steps ? io0.ep_steps + te : nullptr};
         const bool last = !ROLLOUT || t == T_steps - 1;
         uint8_t oc = 0;
-        bool hint_out = false;                             // SPEC: may this env finish at the NEXT step
         T action = action_next;
         if constexpr (POLICY) {
             constexpr int DP = 5 + 3 * NS;                // compile-time obs width (packed shapes)
@@ -1524,7 +1385,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             auto before_traffic = [&](const OwnCtx<T>&) {
                 if constexpr (!AUTO_RESET) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); }
             };
-            Seen<T> r = observe<T, C, G, PACKED, FAST, SPEC>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
+            Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
                                                              ROLLOUT ? &trig : nullptr, before_traffic);
 
             // game.py:249-292 evaluate()
@@ -1543,7 +1404,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             oc = (steps > p.max_steps) ? 3 : (r.collided ? 2 : (at_goal ? 1 : 0));
             total = total + rw;                                               // :287
             if (!active) oc = 0;                          // a padding lane never finishes anything
-            if constexpr (SPEC) hint_out = r.near || may_reach_goal(p, o.v, r.d_goal) || steps >= p.max_steps;
             if (j == 0 && active) {
                 io.reward[el] = rw;
                 io.done[el] = oc != 0;
@@ -1568,73 +1428,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // ONE tile flush below.  (Resetting after the flush cost a second store round at the very
             // end of the kernel -- ~12 scattered 4-byte stores per entity lane plus a re-flush of the
             // row: 0.8 us of the 7.7 us launch at 65 536 x 8.)
-            bool fresh = false, fresh_const = false;
+            bool fresh = false, same_consts = false;
             unsigned long long dm = __ballot(oc != 0 && j == 0);
-            if constexpr (SPEC) {
-                // ---- commit: a finished env whose next episode was generated in the load shadow takes it from its
-                // slot -- one batch of LDS reads, the row swap, register selects; nothing is computed here.
-                const unsigned long long fm = dm & spec_mask;
-                if (dm != 0 && fm != 0) {
-                    using SL = SlotLayout<T, NS>;
-                    using RS = ResetSlots<NS>;
-                    wave_lds_fence();                     // every row of the tile and every slot is complete
-                    // slot lanes: the finished episode's last observation out, the new episode's first one in
-                    const int slot = lane / RS::STRIDE, ent = lane % RS::STRIDE;
-                    const bool swap = spec_src >= 0 && ((fm >> (spec_src & 63)) & 1ull) != 0;
-                    const int e_s = (spec_src & 63) / G;
-                    T* row_s = tile + e_s * D;
-                    const T* slot_s = scratch + slot * SL::STRIDE;
-                    constexpr int PASSES = (5 + 3 * NS + RS::STRIDE - 1) / RS::STRIDE;
-                    T old_v[PASSES], new_v[PASSES];
-#pragma unroll
-                    for (int q = 0; q < PASSES; ++q) {
-                        const int i = ent + q * RS::STRIDE;
-                        const bool ok = swap && i < D;
-                        old_v[q] = ok ? row_s[i] : T(0);
-                        new_v[q] = ok ? slot_s[SL::OBS + i] : T(0);
-                    }
-                    // owner lanes: their part of the new traffic block, the player's heading, the new episode's hint
-                    const bool mine = ((fm >> (lane & ~(G - 1))) & 1ull) != 0;
-                    const int k_own = __popcll(spec_mask & ((1ull << (lane & ~(G - 1))) - 1ull));
-                    const T* slot_o = scratch + (mine ? k_own : 0) * SL::STRIDE;
-                    using V = Vec<T, C>;
-                    Traffic<T, C> nt;
-                    nt.x = *reinterpret_cast<const V*>(slot_o + j * C);
-                    nt.y = *reinterpret_cast<const V*>(slot_o + NS + j * C);
-                    nt.psi = *reinterpret_cast<const V*>(slot_o + 2 * NS + j * C);
-                    nt.v = *reinterpret_cast<const V*>(slot_o + 3 * NS + j * C);
-                    const T n_psi = slot_o[SL::OWN_PSI], n_hint = slot_o[SL::HINT];
-                    wave_lds_fence();                     // the reads above precede the row rewrite
-#pragma unroll
-                    for (int q = 0; q < PASSES; ++q) {
-                        const int i = ent + q * RS::STRIDE;
-                        if (swap && i < D) {
-                            if (io.term_obs) (io.term_obs + e_s * D)[i] = old_v[q];
-                            row_s[i] = new_v[q];          // environment.py:44-48: the new episode's first observation
-                        }
-                    }
-                    if (mine) {
-                        if (j == 0) {
-                            if (io.ep_return) io.ep_return[el] = total;
-                            if (io.ep_steps) io.ep_steps[el] = steps;
-                        }
-                        fresh_const = o.v == (T)rp.own_v && o.gx == (T)rp.goal_x && o.gy == (T)rp.goal_y;
-                        tr = nt;
-                        o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, n_psi, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-                        steps = 1;                                            // environment.py:47
-                        total = T(0);
-                        episode += 1u;
-                        fresh = true;
-                        hint_out = n_hint != T(0);
-                        const int i0 = el * N + j * C;
-                        *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
-                        *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
-                    }
-                    dm &= ~fm;
-                    if (s.stats && lane == 0) atomicAdd(s.stats + 0, (uint32_t)__popcll(fm));
-                }
-                if (dm != 0 && s.stats && lane == 0) atomicAdd(s.stats + 1, (uint32_t)__popcll(dm));
-            }
             constexpr bool SLOTTED = ResetSlots<NS>::SLOTS >= 2;      // N + 1 <= 32: several envs per pass
             if constexpr (SLOTTED) {
                 using SL = SlotLayout<T, NS>;
@@ -1652,20 +1447,19 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                             if (io.ep_return) io.ep_return[el] = total;
                             if (io.ep_steps) io.ep_steps[el] = steps;
                         }
-#pragma unroll
-                        for (int k = 0; k < C; ++k) {
-                            const int n = j * C + k;
-                            tr.x.v[k] = scr[n]; tr.y.v[k] = scr[N + n];
-                            tr.psi.v[k] = scr[2 * N + n]; tr.v.v[k] = scr[3 * N + n];
-                        }
+                        using V = Vec<T, C>;              // the slot's blocks are aligned like the live traffic block
+                        tr.x = *reinterpret_cast<const V*>(scr + j * C);
+                        tr.y = *reinterpret_cast<const V*>(scr + N + j * C);
+                        tr.psi = *reinterpret_cast<const V*>(scr + 2 * N + j * C);
+                        tr.v = *reinterpret_cast<const V*>(scr + 3 * N + j * C);
+                        // own_v / goal are the configuration's: stored only where an injected state had others
+                        same_consts = o.v == (T)rp.own_v && o.gx == (T)rp.goal_x && o.gy == (T)rp.goal_y;
                         o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, scr[SL::OWN_PSI], (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
                         steps = 1;                                            // environment.py:47
                         total = T(0);
                         episode += 1u;
                         fresh = true;
-                        hint_out = true;                  // not worked out on this path: "may finish" is always safe
                         trig.valid = false; trig.dirty = false;   // new headings (stored below)
-                        using V = Vec<T, C>;
                         const int i0 = el * N + j * C;
                         *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
                         *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
@@ -1710,18 +1504,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             if (active && j == 0) {
                 if (fresh) {                              // per-episode constants of the new episode
                     s.episode[el] = episode;
-                    if (!fresh_const) { s.own_v[el] = o.v; s.goal_x[el] = o.gx; s.goal_y[el] = o.gy; }
+                    if (!same_consts) { s.own_v[el] = o.v; s.goal_x[el] = o.gx; s.goal_y[el] = o.gy; }
                 }
                 if (last || fresh) {
                     s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
                     s.steps[el] = steps;
                     s.total_reward[el] = total;
                 }
-#ifndef ACAS2D_EXP_NO_HINT_STORE
-                if constexpr (SPEC) s.hint[el] = hint_out ? 1 : 0;
-#else
-                if constexpr (SPEC) { if (hint_in == 77u) s.hint[el] = hint_out ? 1 : 0; }
-#endif
             }
         }
         // Flush the tile (generic walk: now, the stores drain while finished envs are reset below).
@@ -1756,8 +1545,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
 }
 
 // ACAS2DEnv.reset(), environment.py:44-48 (do_init != 0: fresh episodes; == 0: keep the injected state).
-// HINT (shapes whose step kernel can speculate): also the selected envs' "may finish at the next step" flags.
-template <typename T, int C, int G, bool PACKED, bool FAST, bool HINT>
+template <typename T, int C, int G, bool PACKED, bool FAST>
 __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetParams rp, State<T> s_arg,
                                                        const uint8_t* __restrict__ mask, T* obs,
                                                        int do_init, uint32_t k0, uint32_t k1,
@@ -1787,13 +1575,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
             o = Own<T>{s.own_x[el], s.own_y[el], s.own_psi[el], s.own_v[el], T(0), s.goal_x[el], s.goal_y[el]};
             steps = s.steps[el];
         }
-        bool hint_out = true;                              // no observation, no distances: "may finish" is always safe
         if (obs) {
             steps += 1;
             T d_sep = T(0);
             auto sep = [&](const OwnCtx<T>&) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); };
-            const Seen<T> r = observe<T, C, G, PACKED, FAST, HINT>(p, s, o, el, j, N, steps, false, tr, row, true, nullptr, sep);
-            if constexpr (HINT) hint_out = r.near || may_reach_goal(p, o.v, r.d_goal) || steps >= p.max_steps;
+            const Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row, true, nullptr, sep);
             if (s.trace && j == 0)                        // game.py:132-160: the records' first entries
                 write_trace<T, FAST>(p, s.trace + el * kTraceWidth, o.psi, d_sep, T(0), r.h_goal, r.d_goal, r.d_dev, r.v_closing0,
                                      r.d_cpa0, step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev));
@@ -1805,7 +1591,6 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
             s.steps[el] = steps;
             s.total_reward[el] = T(0);
             s.status[el] = 0;
-            if constexpr (HINT) { if (s.hint) s.hint[el] = hint_out ? 1 : 0; }
         }
     }
 }
@@ -1813,9 +1598,6 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
 // ---- host-side launchers (instantiated per element type in acas2d_f32.hip / acas2d_f64.hip) ----
 struct Shape { int C, G; bool packed; };
 Shape choose_shape(int n_traffic, int elem_size);
-// shapes whose step kernel has a speculating variant (must agree with step_kernel's static_assert)
-constexpr bool spec_shape_ok(int C, int G, bool packed) { return packed && C * G + 1 <= 32; }
-
 template <typename T>
 int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, uint32_t flags,
                 uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream);

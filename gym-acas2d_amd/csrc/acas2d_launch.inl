@@ -39,7 +39,7 @@ template <typename T>
 static State<T> make_state(const Acas2dState& s) {
     return State<T>{(T*)s.own_x, (T*)s.own_y, (T*)s.own_psi, (T*)s.own_v, (T*)s.goal_x, (T*)s.goal_y,
                     (T*)s.trf_x, (T*)s.trf_y, (T*)s.trf_psi, (T*)s.trf_v, s.steps,
-                    (T*)s.total_reward, s.status, s.episode, (T*)s.trace, s.hint, s.stats};
+                    (T*)s.total_reward, s.status, s.episode, (T*)s.trace};
 }
 
 static bool state_complete(const Acas2dState* s) {
@@ -69,8 +69,7 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
     int64_t scratch = 0;
     if (sh.packed && n_traffic + 1 <= 32) {
         int stride = 2; while (stride < n_traffic + 1) stride *= 2;
-        const int64_t obs_at = (4 * (int64_t)n_traffic + 2 + W - 1) / W * W;
-        scratch = (64 / stride) * ((obs_at + 5 + 3 * (int64_t)n_traffic + W - 1) / W * W);
+        scratch = (64 / stride) * ((4 * (int64_t)n_traffic + 1 + W - 1) / W * W);
     } else if (sh.packed) {
         scratch = 4 * (int64_t)n_traffic + 1;
     }
@@ -88,13 +87,6 @@ template <typename T, int C, int G, bool PACKED>
 static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, const Params<T>& p,
                        const ResetParamsT<T>& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
                        int64_t env_offset, int64_t n_envs, int N) {
-    if constexpr (spec_shape_ok(C, G, PACKED)) {
-        if (auto_reset && s.hint) {           // the speculating variant: next episodes generated in the load shadow
-            hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false, false, true>), dim3(g.grid), dim3(kBlock),
-                               g.lds_bytes, stream, p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
-            return;
-        }
-    }
     if (auto_reset)
         hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
                            p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
@@ -124,7 +116,7 @@ template <typename T, int C, int G, bool PACKED>
 static void reset_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
                         const State<T>& s, const uint8_t* mask, T* obs, int do_init, uint32_t k0, uint32_t k1,
                         int64_t env_offset, int64_t n_envs, int N) {
-    hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, kFast, spec_shape_ok(C, G, PACKED)>), dim3(g.grid), dim3(kBlock),
+    hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, kFast>), dim3(g.grid), dim3(kBlock),
                        g.lds_bytes, stream, p, rp, s, mask, obs, do_init, k0, k1, env_offset, n_envs, N, g.tile_elems);
 }
 

@@ -94,9 +94,10 @@ class GameView:
 
 
 class ACAS2DEnv:
-    metadata = {"render.modes": ["human"]}
+    metadata = {"render.modes": ["human", "rgb_array"]}
 
     def __init__(self, n_traffic=1, device="cuda", config=None, record_paths=True):
+        self._window = None
         self.config = config if config is not None else ACAS2DConfig(n_traffic=n_traffic)
         self._vec = ACAS2DVecEnv(1, device=device, dtype=torch.float64, auto_reset=False,
                                  config=self.config, record_trace=record_paths)
@@ -161,10 +162,26 @@ class ACAS2DEnv:
         return host[:D].astype(np.float64), float(host[D]), bool(host[D + 1] != 0), {}
 
     def render(self, mode="human"):
-        """The pygame HUD (game.py:316-431) is split out of the GPU path; no-op here."""
+        """environment.py:50-51 -> ACAS2DGame.view() (game.py:316-431), on a host copy of the state, off the GPU
+        path (render.py).  "human": a pygame window like the reference's (RendererUnavailable if pygame is not
+        installed); "rgb_array": the frame as uint8 [1000, 1600, 3] from the NumPy rasteriser.  As in the
+        reference, closing the window sets `env.game.quit`."""
+        from . import render as R
+        scene = R.Scene.from_env(self)
+        if mode == "rgb_array":
+            return R.rgb_array(scene)
+        if mode != "human":
+            raise ValueError("render mode %r (metadata['render.modes'] = %s)" % (mode, self.metadata["render.modes"]))
+        if self._window is None:
+            self._window = R.PygameWindow()
+        if not self._window.draw(scene):
+            self.game.quit = True                       # game.py:318-321
         return None
 
     def close(self):
+        if self._window is not None:
+            self._window.close()
+            self._window = None
         self._vec.close()
 
     def seed(self, seed=None):

@@ -16,7 +16,7 @@ AUTO_RESET = 1
 class CState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi",
-        "trf_v", "steps", "total_reward", "status", "episode", "hint", "trace", "stats")]
+        "trf_v", "steps", "total_reward", "status", "episode", "trace")]
 
 
 class CStepIO(C.Structure):

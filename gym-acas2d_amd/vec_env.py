@@ -93,19 +93,12 @@ class ACAS2DVecEnv:
     record_trace   (auto_reset=False only) keep `trace` [E, 16]: the per-step record row behind
                    testing_main.py:114-138's CSV columns (include/acas2d.h, Acas2dState.trace;
                    TRACE_COLUMNS below), rewritten by every reset*() / set_state(observe=True) / step()
-    speculative_reset  keep `hint` [E] (include/acas2d.h, Acas2dState.hint): every step flags the envs that
-                   may finish at the next one, and the next step generates their next episodes while its
-                   loads are in flight, so that re-initialising a finished env does not sit at the end
-                   of the launch; results are bit-identical with and without it
-    count_resets   (tests / diagnostics) keep `reset_stats`: finished envs re-initialised from a
-                   speculatively generated episode / inside the step
     """
 
-    metadata = {"render.modes": []}
+    metadata = {"render.modes": ["rgb_array", "human"]}
 
     def __init__(self, num_envs, n_traffic=1, device="cuda", dtype=torch.float32, seed=13,
-                 env_offset=0, auto_reset=True, keep_terminal_obs=True, config=None, speculative_reset=True,
-                 record_trace=False, count_resets=False):
+                 env_offset=0, auto_reset=True, keep_terminal_obs=True, config=None, record_trace=False):
         if config is None:
             config = ACAS2DConfig(n_traffic=n_traffic)
         self.config = config
@@ -137,9 +130,6 @@ class ACAS2DVecEnv:
         self.total_reward = z(E)
         self.status = z(E, dt=torch.uint8)
         self.episode = z(E, dt=torch.int32)            # bit pattern of the u32 counter
-        # 1 = "may finish": the safe value wherever nothing has worked the flag out yet
-        self.hint = torch.ones(E, dtype=torch.uint8, device=dev) if (speculative_reset and auto_reset) else None
-        self.stats = z(4, dt=torch.int32) if count_resets else None
         if record_trace and auto_reset:
             raise ValueError("record_trace needs auto_reset=False (the reference's single-env semantics)")
         self.trace = z(E, len(TRACE_COLUMNS) + 3) if record_trace else None
@@ -177,20 +167,6 @@ class ACAS2DVecEnv:
             self.env_offset, self.num_envs, self.n_traffic, self._stream()))
 
     # ---- gym / VecEnv surface -------------------------------------------------------------------
-    def invalidate_hints(self):
-        """After anything but step() / reset*() / set_state() changed the state (a fused rollout, a restored
-        checkpoint): every env counts as "may finish" until the next step has worked its flag out again."""
-        if self.hint is not None:
-            self.hint.fill_(1)
-
-    def reset_stats(self):
-        """Diagnostics (count_resets=True): {"speculated": finished envs re-initialised from an episode generated
-        in the load shadow, "in_step": finished envs re-initialised inside the step} since construction."""
-        if self.stats is None:
-            return None
-        c = self.stats.cpu().tolist()
-        return {"speculated": c[0], "in_step": c[1]}
-
     def seed(self, seed=None):
         if seed is not None:
             self.seed_value = int(seed)
@@ -319,7 +295,6 @@ class ACAS2DVecEnv:
             native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), T, self.seed_value,
                             self.env_offset, E, self.n_traffic, self._stream()))
             self._obs.copy_(out["obs"][T - 1])        # outputs["obs"] stays "the latest observation"
-            self.invalidate_hints()                   # the rollout kernels do not maintain the hints
         out["_actions"] = a          # keep the (possibly re-laid-out) input alive until the launch ran
         return out
 
@@ -364,7 +339,6 @@ class ACAS2DVecEnv:
             native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), C.byref(pol), ptr(self._obs),
                             T, self.seed_value, self.env_offset, E, self.n_traffic, self._stream()))
             self._obs.copy_(out["obs"][T - 1])        # the observation the NEXT action would be taken on
-            self.invalidate_hints()                   # the rollout kernels do not maintain the hints
         out["_weights"] = keep       # keep the transposed copies alive until the launch ran
         return out
 
@@ -381,8 +355,19 @@ class ACAS2DVecEnv:
     def close(self):
         self._closed = True
 
-    def render(self, mode="human"):
-        raise NotImplementedError("rendering is split out of the GPU path (reference game.py:316-431)")
+    def render(self, mode="rgb_array", index=0):
+        """One env's frame from a host copy of its state (render.py; reference game.py:316-431), off the step
+        path: "rgb_array" -> uint8 [1000, 1600, 3]; "human" -> a pygame window (RendererUnavailable without pygame)."""
+        from . import render as R
+        scene = R.Scene.from_env(self, index)
+        if mode == "rgb_array":
+            return R.rgb_array(scene)
+        if mode != "human":
+            raise ValueError("render mode %r" % (mode,))
+        if getattr(self, "_window", None) is None:
+            self._window = R.PygameWindow()
+        self._window.draw(scene)
+        return None
 
     # ---- SB3 VecEnv shims (training_main.py hands the env to SB3) -------------------------------
     def get_attr(self, attr_name, indices=None):
@@ -409,7 +394,6 @@ class ACAS2DVecEnv:
     def load_state_dict(self, sd):
         for n, v in sd.items():
             getattr(self, n).copy_(v)
-        self.invalidate_hints()
 
     def algorithmic_bytes_per_step(self):
         s = 4 if self.dtype == torch.float32 else 8

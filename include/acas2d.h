@@ -29,8 +29,6 @@
  *                                                    (game.running/outcome, game.py:36,39)
  *   episode                                u32[E]    reset counter (input of the reset RNG)
  *   actions T[E]; obs T[E][D] row-major; reward T[E]; done u8[E]; outcome u8[E]
- *   hint                                   u8[E]     optional: "this env may finish at the next step" -- what the
- *                                                    step kernels' speculative reset works from, see Acas2dState
  */
 #ifndef ACAS2D_H
 #define ACAS2D_H
@@ -98,22 +96,6 @@ typedef struct Acas2dState {
     void *total_reward;
     uint8_t *status;
     uint32_t *episode;
-    /* Optional (NULL = off): u8[E], maintained by the library.  hint[e] != 0 says that env e MAY finish at its
-     * next step (conservatively: one step moves the player by v dt and an aircraft by v_k dt, so an env whose
-     * aircraft are all further than the collision distance + (v + v_k) dt apart, whose goal is further than the
-     * goal radius + v dt away and whose step counter is below the limit cannot finish -- about 1 % of the envs
-     * are flagged at the default configuration).  With ACAS2D_AUTO_RESET a finished env needs
-     * ACAS2DGame.__init__ (game.py:80-116: one RNG block per aircraft) plus the new episode's first observe()
-     * before its step can return -- a long dependent chain at the very end of the launch, on the wave every
-     * other wave then waits for.  acas2d_step_* (packed work shapes with n_traffic <= 31, both element types)
-     * loads hint first and generates the next episode of every flagged env while the rest of its loads are in
-     * flight; a flagged env that does finish is then re-initialised by copies and register selects.  Every
-     * acas2d_step_* / acas2d_reset_* that has the buffer rewrites the flags of the envs it touches
-     * (acas2d_reset_* without an observation: 1).  Results NEVER depend on the flags -- an env that finishes
-     * unflagged is re-initialised inside the step as without the buffer -- so a caller that changes state behind
-     * the library's back (or runs acas2d_rollout_*, which neither reads nor writes hint) only loses speed until
-     * the next step has rewritten them; filling the buffer with 1 after such a change avoids even that. */
-    uint8_t *hint;
     /* Optional (NULL = off): T[E][16], the per-step record row behind testing_main.py:114-138's CSV columns
      * (the lists ACAS2DGame appends to, game.py:132-160, :231-241, :266-276):
      *   [0] psi  [1] d_sep (minimum separation AFTER the player moved and BEFORE the traffic did, :236-237)
@@ -123,10 +105,6 @@ typedef struct Acas2dState {
      * Written by acas2d_step_* WITHOUT ACAS2D_AUTO_RESET (the single-env semantics those scripts run) and by
      * acas2d_reset_* when it computes an observation. */
     void *trace;
-    /* Optional (NULL = off; tests and diagnostics): u32[4] event counters, incremented atomically by
-     * acas2d_step_* with ACAS2D_AUTO_RESET: [0] finished envs re-initialised from a speculatively generated
-     * episode, [1] finished envs re-initialised inside the step (packed work shapes only). */
-    uint32_t *stats;
 } Acas2dState;
 
 /* Inputs / outputs of one step, device pointers.  term_obs, ep_return, ep_steps may be NULL. */
@@ -221,8 +199,6 @@ int acas2d_rollout_policy_f64(const Acas2dConfig *cfg, const Acas2dState *state,
  *   do_init == 0: keep the state the caller wrote into the buffers (oracle-state injection /
  *                 host-side MT19937 "parity reset"), only zero total_reward and status;
  * then, if obs != NULL, run observe(): steps += 1 and the first observation into obs[e].
- * If state->hint != NULL the selected envs' flags are rewritten (from the observation's distances; 1 when
- * obs == NULL).
  */
 int acas2d_reset_f32(const Acas2dConfig *cfg, const Acas2dState *state, const uint8_t *mask,
                      void *obs, int32_t do_init, uint64_t seed, int64_t env_offset,

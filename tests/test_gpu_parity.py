@@ -493,7 +493,7 @@ def test_f32_statistical_single_step_vs_f64_oracle(g, O):
 
 def test_f32_reset_names_the_same_episodes(g, O):
     """(seed, global env index, episode counter) names ONE episode per element type, whichever path draws
-    it: reset() / reset_masked() (reset_kernel), the auto-reset inside a step and the speculative generation all call
+    it: reset() / reset_masked() (reset_kernel) and the auto-reset inside a step (both of its walks) call
     the same per-entity function.  The float32 build evaluates the draws in float32 (24 random bits):
     equal to the float64 oracle up to float32 rounding of the 1600-px / 360-degree ranges (positions
     2.5e-4, headings 6e-5); the float64 build is bit-equal to the oracle (test_f64_auto_reset_vs_oracle)."""
@@ -508,18 +508,16 @@ def test_f32_reset_names_the_same_episodes(g, O):
             assert np.minimum(dpsi, 360 - dpsi).max() < 6e-5, name
         assert np.array_equal(env.trf_v[sel], ref.trf_v[sel])
 
-    for spec in (True, False):
+    for spec in (True,):
         ref = O.OracleEnvs(E, N, seed=5, auto_reset=True)
         ref.reset()
         env = GpuEngine(g, E, N, dtype=torch.float32, auto_reset=True, seed=5)
-        if not spec:
-            env.v = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, auto_reset=True, seed=5, speculative_reset=False)
         env.reset()
         close_to_oracle(env, np.ones(E, bool))
         # step both with the same actions until plenty of envs have been reset inside the step
         rng = np.random.default_rng(3)
         checked = 0
-        twin = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, auto_reset=True, seed=5, speculative_reset=False)
+        twin = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=torch.float32, auto_reset=True, seed=5)
         for _ in range(40):
             a = rng.uniform(-1, 1, E).astype(np.float32).astype(np.float64)
             _, _, d1, _, _ = ref.step(a)

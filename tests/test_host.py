@@ -88,7 +88,7 @@ def test_c_abi_argument_validation_needs_no_gpu(g):
     assert L.acas2d_step_f64(C.byref(cfg), C.byref(st), C.byref(io), 0, 0, 0, 4, 1, None) == -22
     assert b"state" in L.acas2d_last_error()
     dummy = (C.c_double * 64)()
-    full = g.native.CState(*([C.addressof(dummy)] * 14))        # hint, trace, stats stay NULL
+    full = g.native.CState(*([C.addressof(dummy)] * 14))        # trace stays NULL
     assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), C.byref(io), 0, 0, 0, 4, 1, None) == -22
     assert b"required" in L.acas2d_last_error()
     io_ok = g.native.CStepIO(*([C.addressof(dummy)] * 5 + [None] * 3))

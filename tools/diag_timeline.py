@@ -17,14 +17,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=65536)
 ap.add_argument("--traffic", type=int, default=8)
 ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--spec", action="store_true")
 ap.add_argument("--no-terminations", action="store_true")
 args = ap.parse_args()
 
 g.native.LIB_PATH = os.path.join(ROOT, "gym-acas2d_amd", "csrc", os.environ.get("ACAS2D_DIAG_LIB", "libacas2d_hip_diag.so"))
 g.native._lib = None
 L = g.native.lib()
-env = g.ACAS2DVecEnv(args.envs, args.traffic, device="cuda:0", dtype=torch.float32, seed=13, speculative_reset=args.spec)
+env = g.ACAS2DVecEnv(args.envs, args.traffic, device="cuda:0", dtype=torch.float32, seed=13)
 if args.no_terminations:
     env._ccfg.collision_dist = 0.0; env._ccfg.goal_radius = 0.0; env._ccfg.max_steps = 2 ** 30
 geo = g.native.launch_geometry(args.envs, args.traffic, 4)
