@@ -3,10 +3,15 @@
 The reference trains with Stable-Baselines3 (`training_main.py:44-52`:
 `PPO('MlpPolicy', env, seed=13).learn(1_048_576)`), one env, CPU.  SB3 is not available here and
 its one-env-at-a-time loop is exactly what the batched engine replaces, so this module restates
-the algorithm SB3 1.1.0 runs with the hyper-parameters recorded in the reference's model zips
-(n_steps 2048, batch 64, epochs 10, gamma 0.99, lambda 0.95, clip 0.2, lr 3e-4, ent 0, vf 0.5,
-max-grad-norm 0.5, Adam eps 1e-5, orthogonal init, state-independent log-std, advantages
-normalised per minibatch) on E parallel envs: rollouts, GAE and the updates all stay on the GPU.
+the algorithm SB3 1.1.0 runs (clipped surrogate, advantages normalised per minibatch, value loss
+without clipping, state-independent log-std, orthogonal init, Adam eps 1e-5, gradient-norm clipping)
+on E parallel envs: rollouts, GAE and the updates all stay on the GPU.  `PPOConfig.sb3()` carries the
+hyper-parameters recorded in the reference's model zips (n_steps 2048, batch 64, epochs 10, gamma
+0.99, lambda 0.95, clip 0.2, lr 3e-4, ent 0, vf 0.5, max-grad-norm 0.5); the DEFAULTS differ in the two
+sizes that only make sense for one env (n_steps 128 per env, minibatch 16 384: a choice for E >= 1024,
+stated here so that it is not mistaken for SB3's).  SB3's own semantics stay *parity unpinned*: no SB3
+fixture exists in the reference; what is pinned is the arithmetic of one update (tests/test_ppo.py:
+a float64 NumPy restatement with finite-difference gradients) and graph path == eager path.
 
 The network uses SB3's `MlpPolicy` parameter names (separate 2x64 tanh actor / critic), so the
 reference's trained zips load as initial weights (`ActorCritic.load_sb3_state_dict`) and a policy
@@ -42,6 +47,14 @@ class PPOConfig:
     vf_coef: float = 0.5
     max_grad_norm: float = 0.5
     seed: int = 13                # settings.py:28
+
+    @classmethod
+    def sb3(cls, **overrides):
+        """The values SB3 1.1.0's PPO ran the reference's training with (training_main.py:44-52 passes none, so
+        these are SB3's defaults as recorded in models/**/*.zip): sized for ONE env -- with E envs the buffer
+        is E x 2048 samples cut into minibatches of 64."""
+        return cls(**{**dict(n_steps=2048, batch_size=64, n_epochs=10, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
+                             learning_rate=3e-4, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5), **overrides})
 
 
 def _ortho(layer, gain):
@@ -80,7 +93,7 @@ class ActorCritic(nn.Module):
                                           self.action_net.weight, self.action_net.bias))
 
     def forward(self, obs):
-        x = obs.to(torch.float32)
+        x = obs.to(self.log_std.dtype)                     # float32 (SB3 casts observations the same way)
         mean = self.action_net(self.mlp_extractor.policy_net(x))
         value = self.value_net(self.mlp_extractor.value_net(x)).squeeze(-1)
         return mean, value
@@ -120,6 +133,21 @@ def _normal_logp(mean, log_std, x):
     return (-((x - mean) ** 2) / (2.0 * (2.0 * log_std).exp()) - log_std - LOG_SQRT_2PI).sum(-1)
 
 
+def ppo_loss(policy, cfg, obs, act, old_logp, adv, ret):
+    """SB3 1.1.0 PPO.train() for one minibatch of a Box(1) action space: advantages normalised over the
+    minibatch, clipped surrogate, plain MSE value loss (clip_range_vf = None), entropy of the state-independent
+    Gaussian.  The ONE loss both the captured and the op-by-op update run.  Returns (loss, pg, vf)."""
+    mean, value = policy.forward(obs)
+    log_std = policy.log_std
+    logp = _normal_logp(mean, log_std, act)
+    a = (adv - adv.mean()) / (adv.std() + 1e-8)
+    ratio = (logp - old_logp).exp()
+    pg = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+    vf = torch.nn.functional.mse_loss(value, ret)
+    ent = -(0.5 + LOG_SQRT_2PI + log_std).sum()           # -entropy of N(., exp(log_std)), the same for every state
+    return pg + cfg.ent_coef * ent + cfg.vf_coef * vf, pg, vf
+
+
 class PPOTrainer:
     def __init__(self, venv, config=None, policy=None, use_graphs=None):
         self.venv = venv
@@ -146,13 +174,14 @@ class PPOTrainer:
     def _alloc(self):
         E, T, D, dev = self.venv.num_envs, self.cfg.n_steps, self.venv.obs_dim, self.device
         f32 = dict(dtype=torch.float32, device=dev)
-        self.b_obs = torch.empty(T, E, D, **f32)
-        self.b_act = torch.empty(T, E, 1, **f32)
-        self.b_logp, self.b_val, self.b_rew = (torch.empty(T, E, **f32) for _ in range(3))
-        self.b_adv, self.b_ret, self.b_epret = (torch.empty(T, E, **f32) for _ in range(3))
-        self.b_done = torch.empty(T, E, dtype=torch.bool, device=dev)
-        self.b_eplen = torch.empty(T, E, dtype=torch.int32, device=dev)
-        self.b_outcome = torch.empty(T, E, dtype=torch.uint8, device=dev)
+        # zeros, not empty: the capture warm-up below runs GAE and two updates over the whole buffer
+        self.b_obs = torch.zeros(T, E, D, **f32)
+        self.b_act = torch.zeros(T, E, 1, **f32)
+        self.b_logp, self.b_val, self.b_rew = (torch.zeros(T, E, **f32) for _ in range(3))
+        self.b_adv, self.b_ret, self.b_epret = (torch.zeros(T, E, **f32) for _ in range(3))
+        self.b_done = torch.zeros(T, E, dtype=torch.bool, device=dev)
+        self.b_eplen = torch.zeros(T, E, dtype=torch.int32, device=dev)
+        self.b_outcome = torch.zeros(T, E, dtype=torch.uint8, device=dev)
         self.t_idx = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def _collect_step(self):
@@ -187,34 +216,32 @@ class PPOTrainer:
         self.b_adv.copy_(adv)
         self.b_ret.copy_(ret)
 
-    def _minibatch(self):
-        """One PPO minibatch update on the rows named by the static index buffer."""
-        cfg, idx = self.cfg, self.mb_idx
+    def _minibatch(self, idx):
+        """One PPO minibatch update on the rows named by a static index buffer."""
         T, E = self.cfg.n_steps, self.venv.num_envs
         flat = lambda x: x.reshape(T * E, *x.shape[2:])  # noqa: E731
-        obs, act = flat(self.b_obs)[idx], flat(self.b_act)[idx]
-        old_logp, a, ret = flat(self.b_logp)[idx], flat(self.b_adv)[idx], flat(self.b_ret)[idx]
-        # (torch.distributions validates its arguments with a host read: not capturable)
-        mean, value = self.policy.forward(obs)
-        log_std = self.policy.log_std
-        logp = _normal_logp(mean, log_std, act)
-        a = (a - a.mean()) / (a.std() + 1e-8)
-        ratio = (logp - old_logp).exp()
-        pg = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
-        vf = torch.nn.functional.mse_loss(value, ret)
-        ent = -(0.5 + LOG_SQRT_2PI + log_std).sum()       # Normal entropy, state-independent
-        loss = pg + cfg.ent_coef * ent + cfg.vf_coef * vf
+        # (torch.distributions validates its arguments with a host read: not capturable -- ppo_loss() does not use it)
+        loss, pg, vf = ppo_loss(self.policy, self.cfg, flat(self.b_obs)[idx], flat(self.b_act)[idx],
+                                flat(self.b_logp)[idx], flat(self.b_adv)[idx], flat(self.b_ret)[idx])
         loss.backward()
-        nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
+        nn.utils.clip_grad_norm_(self.policy.parameters(), self.cfg.max_grad_norm)
         self.opt.step()
         return pg.detach(), vf.detach()
 
     def _capture(self):
         """Warm the three bodies up on a side stream, then capture them (PyTorch's whole-network
-        capture recipe: gradients are None at capture time, so backward assigns static buffers)."""
+        capture recipe: gradients are None at capture time, so backward assigns static buffers).
+        The warm-up steps the env and takes real optimizer steps on an all-zero buffer: the env, the
+        observation, the parameters and the Adam state are put back IN PLACE afterwards (the graphs
+        hold their addresses), so training starts from exactly the state it was constructed in."""
         self._alloc()
         n = self.cfg.n_steps * self.venv.num_envs
-        self.mb_idx = torch.zeros(min(self.cfg.batch_size, n), dtype=torch.int64, device=self.device)
+        B = min(self.cfg.batch_size, n)
+        self.mb_idx = torch.zeros(B, dtype=torch.int64, device=self.device)
+        self.mb_tail = torch.zeros(n % B, dtype=torch.int64, device=self.device) if n % B else None
+        env_before = self.venv.state_dict()
+        obs_before, env_obs_before = self.obs.clone(), self.venv.outputs["obs"].clone()
+        params_before = [p.detach().clone() for p in self.policy.parameters()]
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -223,9 +250,10 @@ class PPOTrainer:
                     self.t_idx.zero_()
                     self._collect_step()
                 self._gae()
-            for _ in range(2):
-                self.opt.zero_grad(set_to_none=True)
-                self._minibatch()
+            for idx in (self.mb_idx, self.mb_idx, self.mb_tail):
+                if idx is not None:
+                    self.opt.zero_grad(set_to_none=True)
+                    self._minibatch(idx)
         torch.cuda.current_stream(self.device).wait_stream(side)
         g_step, g_gae, g_upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         self.t_idx.zero_()
@@ -236,8 +264,25 @@ class PPOTrainer:
                 self._gae()
         self.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(g_upd):
-            self._pg, self._vf = self._minibatch()
-        self._graphs = (g_step, g_gae, g_upd)
+            self._pg, self._vf = self._minibatch(self.mb_idx)
+        g_tail = None
+        if self.mb_tail is not None:                      # the last, partial minibatch of an epoch: its own static shape
+            g_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_tail):
+                self._minibatch(self.mb_tail)
+        self._graphs = (g_step, g_gae, g_upd, g_tail)
+        with torch.no_grad():
+            for p, q in zip(self.policy.parameters(), params_before):
+                p.copy_(q)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()                         # exp_avg, exp_avg_sq, step: a fresh Adam
+            self.venv.load_state_dict(env_before)
+            self.venv.outputs["obs"].copy_(env_obs_before)
+            self.obs.copy_(obs_before)
+            self.nan_events.zero_()
+            self.t_idx.zero_()
 
     def collect(self):
         cfg, E, T = self.cfg, self.venv.num_envs, self.cfg.n_steps
@@ -289,9 +334,12 @@ class PPOTrainer:
             n, B = cfg.n_steps * self.venv.num_envs, self.mb_idx.numel()
             for _ in range(cfg.n_epochs):
                 perm = torch.randperm(n, device=self.device)
-                for i in range(0, n - B + 1, B):          # whole minibatches (static shapes)
+                for i in range(0, n - B + 1, B):          # whole minibatches: one static shape
                     self.mb_idx.copy_(perm[i:i + B])
                     self._graphs[2].replay()
+                if self.mb_tail is not None:              # ... and the partial one SB3 also takes, its own graph
+                    self.mb_tail.copy_(perm[n - n % B:])
+                    self._graphs[3].replay()
             return {"pg_loss": self._pg.item(), "value_loss": self._vf.item(),
                     "std": self.policy.log_std.detach().exp().item()}
         n = obs.shape[0]
@@ -300,15 +348,7 @@ class PPOTrainer:
             perm = torch.randperm(n, device=self.device)
             for i in range(0, n, cfg.batch_size):
                 idx = perm[i:i + cfg.batch_size]
-                dist, value = self.policy.distribution(obs[idx])
-                logp = dist.log_prob(act[idx]).sum(-1)
-                a = adv[idx]
-                a = (a - a.mean()) / (a.std() + 1e-8)
-                ratio = (logp - old_logp[idx]).exp()
-                pg = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
-                vf = torch.nn.functional.mse_loss(value, ret[idx])
-                ent = -dist.entropy().sum(-1).mean()
-                loss = pg + cfg.ent_coef * ent + cfg.vf_coef * vf
+                loss, pg, vf = ppo_loss(self.policy, cfg, obs[idx], act[idx], old_logp[idx], adv[idx], ret[idx])
                 self.opt.zero_grad(set_to_none=True)
                 loss.backward()
                 nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)

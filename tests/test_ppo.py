@@ -45,6 +45,80 @@ def test_actor_critic_has_sb3_layout_and_loads_the_reference_policy():
     assert fresh.log_std.detach().item() == 0.0 and fresh.action_net.weight.abs().max() < 0.05   # SB3 init gains
 
 
+def _np_loss(theta, shapes, cfg, obs, act, old_logp, adv, ret):
+    """ppo_loss() restated in float64 NumPy from SB3 1.1.0's PPO.train(): separate 2 x 64 tanh actor / critic,
+    Gaussian log-prob, per-minibatch advantage normalisation (torch.std: Bessel-corrected), clipped surrogate,
+    MSE value loss, entropy bonus."""
+    p, k = {}, 0
+    for name, shp in shapes:
+        n = int(np.prod(shp))
+        p[name] = theta[k:k + n].reshape(shp)
+        k += n
+
+    def mlp(prefix, x):
+        h = np.tanh(x @ p[prefix + ".0.weight"].T + p[prefix + ".0.bias"])
+        return np.tanh(h @ p[prefix + ".2.weight"].T + p[prefix + ".2.bias"])
+
+    mean = mlp("mlp_extractor.policy_net", obs) @ p["action_net.weight"].T + p["action_net.bias"]
+    value = (mlp("mlp_extractor.value_net", obs) @ p["value_net.weight"].T + p["value_net.bias"])[:, 0]
+    log_std = p["log_std"]
+    logp = (-((act - mean) ** 2) / (2.0 * np.exp(2.0 * log_std)) - log_std - 0.5 * np.log(2.0 * np.pi)).sum(-1)
+    a = (adv - adv.mean()) / (adv.std(ddof=1) + 1e-8)
+    ratio = np.exp(logp - old_logp)
+    pg = -np.minimum(a * ratio, a * np.clip(ratio, 1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+    vf = ((value - ret) ** 2).mean()
+    ent = -(0.5 + 0.5 * np.log(2.0 * np.pi) + log_std).sum()
+    return pg + cfg.ent_coef * ent + cfg.vf_coef * vf
+
+
+def test_one_minibatch_update_against_a_float64_numpy_restatement():
+    """The arithmetic of ONE update -- loss, gradient (central finite differences of the NumPy restatement: nothing
+    of torch's autograd), global-norm clipping as torch.nn.utils.clip_grad_norm_ does it, the first Adam step
+    (eps 1e-5) -- against the torch path the trainer runs.  SB3 itself stays parity unpinned (no fixture)."""
+    import gym_acas2d_amd as g
+    torch.manual_seed(3)
+    rng = np.random.default_rng(5)
+    D, B = 8, 40
+    cfg = g.PPOConfig(ent_coef=0.01, max_grad_norm=0.5)
+    pol = g.ActorCritic(D).double()
+    with torch.no_grad():
+        pol.action_net.weight.mul_(30.0)                        # away from the near-zero SB3 init: ratios spread, some clip
+        pol.log_std.fill_(-0.3)
+    obs, act = rng.uniform(-1, 1, (B, D)), rng.normal(0, 0.7, (B, 1))
+    adv, ret = rng.normal(0, 2, B), rng.normal(0, 1, B)
+    names = [(k, tuple(v.shape)) for k, v in pol.state_dict().items()]
+    theta = np.concatenate([v.detach().numpy().ravel() for v in pol.state_dict().values()])
+    mean0 = pol.forward(torch.as_tensor(obs))[0].detach().numpy()
+    old_logp = (-((act - mean0) ** 2) / (2 * np.exp(-0.6)) + 0.3 - 0.5 * np.log(2 * np.pi)).sum(-1) + rng.normal(0, 0.25, B)
+    args = (cfg, obs, act, old_logp, adv, ret)
+    loss_t, pg_t, vf_t = g.ppo_loss(pol, cfg, *(torch.as_tensor(x) for x in args[1:]))
+    assert abs(loss_t.item() - _np_loss(theta, names, *args)) < 1e-12
+    ratio = np.exp((-((act - mean0) ** 2) / (2 * np.exp(-0.6)) + 0.3 - 0.5 * np.log(2 * np.pi)).sum(-1) - old_logp)
+    assert ((ratio < 0.8) | (ratio > 1.2)).sum() >= 5 and ((ratio > 0.8) & (ratio < 1.2)).sum() >= 5     # both branches of the clip
+    # gradient by central differences of the restatement
+    grad, h = np.zeros_like(theta), 1e-6
+    for i in range(theta.size):
+        tp, tm = theta.copy(), theta.copy()
+        tp[i] += h
+        tm[i] -= h
+        grad[i] = (_np_loss(tp, names, *args) - _np_loss(tm, names, *args)) / (2 * h)
+    opt = torch.optim.Adam(pol.parameters(), lr=cfg.learning_rate, eps=1e-5)
+    loss_t.backward()
+    g_t = np.concatenate([pol.get_parameter(k).grad.numpy().ravel() for k, _ in names])
+    assert np.abs(g_t - grad).max() < 1e-7 * max(1.0, np.abs(grad).max())
+    torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)
+    opt.step()
+    total = np.sqrt((grad ** 2).sum())
+    assert total > cfg.max_grad_norm                            # the clip is active in this case
+    gc = grad * min(1.0, cfg.max_grad_norm / (total + 1e-6))
+    m_hat, v_hat = gc, gc ** 2                                  # first step: the bias corrections cancel the (1 - beta) factors
+    expect = theta - cfg.learning_rate * m_hat / (np.sqrt(v_hat) + 1e-5)
+    after = np.concatenate([pol.get_parameter(k).detach().numpy().ravel() for k, _ in names])
+    assert np.abs(after - expect).max() < 2e-9, np.abs(after - expect).max()
+    sb3 = g.PPOConfig.sb3()
+    assert (sb3.n_steps, sb3.batch_size, sb3.n_epochs, sb3.max_grad_norm, sb3.learning_rate) == (2048, 64, 10, 0.5, 3e-4)
+
+
 def _eval_on_reference_episodes(g, policy):
     own, trf, goal = H.parity_reset_states(g.ACAS2DConfig(), 13, 0, 100)
     ev = g.ACAS2DVecEnv(100, 1, device="cuda:0", dtype=torch.float64, auto_reset=False)
@@ -69,6 +143,46 @@ def test_short_ppo_run_learns():
     after = _eval_on_reference_episodes(g, tr.policy)
     assert (after["outcome"] == 2).sum() <= 10, np.bincount(after["outcome"], minlength=4)
     assert after["total_reward"].mean() > before["total_reward"].mean() + 50
+
+
+@pytest.mark.gpu
+def test_captured_update_equals_the_op_by_op_update():
+    """One iteration's update from the three hipGraphs == the same update launched op by op, minibatch for
+    minibatch including the partial last one of every epoch (n = 5120 samples, minibatch 2048), from the same
+    batch, the same permutations and the same initial weights; and capturing leaves the trainer as constructed
+    (weights, Adam state, env)."""
+    import gym_acas2d_amd as g
+    cfg = g.PPOConfig(n_steps=20, batch_size=2048, n_epochs=3)
+    mk = lambda: g.ACAS2DVecEnv(256, 1, device="cuda:0", dtype=torch.float32, seed=13)  # noqa: E731
+    tg, te = g.PPOTrainer(mk(), cfg), g.PPOTrainer(mk(), cfg, use_graphs=False)
+    init = [p.detach().clone() for p in tg.policy.parameters()]
+    for p, q in zip(te.policy.parameters(), init):
+        assert torch.equal(p, q)                               # same seed, same init
+    env0 = {k: v.clone() for k, v in tg.venv.state_dict().items()}
+    tg._capture()
+    for p, q in zip(tg.policy.parameters(), init):
+        assert torch.equal(p, q)                               # the warm-up's optimizer steps were undone in place
+    assert all(float(v.abs().sum()) == 0 for st in tg.opt.state.values() for v in st.values() if torch.is_tensor(v))
+    for k, v in tg.venv.state_dict().items():
+        assert torch.equal(v, env0[k]), k
+    assert tg.collect() is None and tg.mb_tail is not None and tg.mb_tail.numel() == 1024
+    flat = lambda x: x.reshape(20 * 256, *x.shape[2:]).clone()  # noqa: E731
+    batch = [flat(b) for b in (tg.b_obs, tg.b_act, tg.b_logp, tg.b_adv, tg.b_ret, tg.b_val)]
+    torch.manual_seed(99)
+    sg = tg.update()
+    torch.manual_seed(99)
+    se = te.update(*batch)
+    with torch.no_grad():
+        pg_, pe_ = (torch.cat([p.reshape(-1) for p in t.policy.parameters()]) for t in (tg, te))
+        p0 = torch.cat([p.reshape(-1) for p in init])
+    worst, moved = float((pg_ - pe_).abs().max()), float((pg_ - p0).abs().max())
+    mean_diff, mean_moved = float((pg_ - pe_).abs().mean()), float((pg_ - p0).abs().mean())
+    # 9 Adam steps of ~lr each.  The two paths differ by float32 summation order only (fused multi-tensor Adam,
+    # atomics in the gather's backward), which Adam's g / (|g| + eps) amplifies for the few parameters whose
+    # gradient is ~0; a dropped or different minibatch would move a third of the steps (>= 0.3 x moved).
+    assert moved > 1e-3 and worst < 0.05 * moved and mean_diff < 0.01 * mean_moved, (worst, moved, mean_diff, mean_moved)
+    # (reported from different minibatches: the captured path's last FULL one, the op-by-op path's partial one)
+    assert abs(sg["value_loss"] - se["value_loss"]) < 0.05 * abs(se["value_loss"])
 
 
 @pytest.mark.gpu
