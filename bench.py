@@ -231,9 +231,9 @@ class StepRunner:
         return n
 
 
-def make_env(g, E, N, dtype, dev, rank, args):
+def make_env(g, E, N, dtype, dev, rank, args, fast_math=False):
     env = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13, env_offset=rank * E,
-                         auto_reset=not args.no_auto_reset)
+                         auto_reset=not args.no_auto_reset, config=g.ACAS2DConfig(n_traffic=N, fast_math=fast_math))
     if args.no_collisions or args.no_terminations:
         env._ccfg.collision_dist = 0.0
     if args.no_terminations:
@@ -248,7 +248,7 @@ def time_config(g, E, N, dtype_name, dev, args, steps=1000, chunk=100):
     steps after a short spin.  Returns the numbers of the roofline line for that workload."""
     import torch
     dtype = torch.float32 if dtype_name == "f32" else torch.float64
-    env = make_env(g, E, N, dtype, dev, 0, args)
+    env = make_env(g, E, N, dtype, dev, 0, args, fast_math=dtype_name == "f64-fast")
     gen = torch.Generator(device=dev).manual_seed(1000)
     actions = torch.rand(chunk, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
     runner = StepRunner(env, actions, True)
@@ -430,7 +430,8 @@ def main():
         if world == 1 and not args.rehearsal and not args.no_extra:
             # the other single-GPU configurations of BASELINE.json (parity-test cases; reported, not `value`)
             extra = []
-            for (e2, n2, d2) in ((4096, 3, "f32"), (65536, 64, "f32"), (65536, 8, "f64"), (131072, 8, "f32")):
+            for (e2, n2, d2) in ((4096, 3, "f32"), (65536, 64, "f32"), (65536, 8, "f64"), (65536, 8, "f64-fast"),
+                                 (131072, 8, "f32")):
                 if (e2, n2, d2) == (E, N, args.dtype):
                     continue
                 try:

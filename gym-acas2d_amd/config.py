@@ -16,7 +16,7 @@ OUTCOME_NAMES = {1: "Goal", 2: "Collision", 3: "Timeout"}  # settings.py:6
 class CConfig(C.Structure):
     """Mirror of ``struct Acas2dConfig`` in include/acas2d.h (field order is the ABI)."""
     _fields_ = [("dt", C.c_double), ("acc_lat_limit", C.c_double), ("max_steps", C.c_int32),
-                ("_pad", C.c_int32)] + [(n, C.c_double) for n in (
+                ("math", C.c_int32)] + [(n, C.c_double) for n in (
                     "collision_dist", "goal_radius", "safe_distance", "d_goal_max", "d_dev_max",
                     "d_sep_max", "d_cpa_max", "v_closing_max", "rw_d_goal_max", "rw_d_dev_max",
                     "reward_goal", "reward_collision", "own_x0", "own_y0", "own_v", "own_heading0",
@@ -41,6 +41,10 @@ class ACAS2DConfig:
     traffic_initial_heading_lim: float = 15  # settings.py:44
     reward_goal: float = 1000               # settings.py:47
     reward_collision: float = -1000         # settings.py:48
+    # not a setting of the reference: which formulation the float64 engine runs (include/acas2d.h, ACAS2D_MATH_*).
+    # False: the reference's operation order with libm (~1e-13 from the CPU reference);  True: the float32
+    # build's algebraic formulation in float64 arithmetic (within 1e-9, more than twice as fast).
+    fast_math: bool = False
 
     def __post_init__(self):
         if self.n_traffic < 1:
@@ -87,6 +91,7 @@ class ACAS2DConfig:
         c.dt = self.dt
         c.acc_lat_limit = self.acc_lat_limit
         c.max_steps = self.max_steps
+        c.math = 1 if self.fast_math else 0                           # ACAS2D_MATH_FAST / _DEFAULT
         c.collision_dist = 2 * self.collision_radius                  # game.py:187
         c.goal_radius = self.goal_radius
         c.safe_distance = self.safe_distance

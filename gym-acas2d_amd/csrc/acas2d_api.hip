@@ -23,6 +23,12 @@ Shape choose_shape(int n, int elem_size) {
     if (n == 1) return Shape{1, 1, true};
     if (n == 2) return Shape{2, 1, true};
     if (n == 3) return Shape{3, 1, true};
+    // float64: 4 aircraft per lane (two 16-byte accesses per field) where N allows -- half the lanes per env, so
+    // half the redundant player-side arithmetic: 20.7 vs 25.0 us per launch at 65 536 x 8 (EXACT), 12.4 vs 15.0 (FAST)
+    if (elem_size == 8 && n % 4 == 0) {
+        const int g = n / 4;
+        if (g <= 64 && (g & (g - 1)) == 0) return Shape{4, g, true};
+    }
     if (n % c16 == 0) {
         const int g = n / c16;
         if (g <= 64 && (g & (g - 1)) == 0) return Shape{c16, g, true};

@@ -1,7 +1,7 @@
 // float64 instantiation (parity mode, EXACT formulation).  Built with -ffp-contract=off: the only
 // fused multiply-adds are the explicit ones that mirror the reference's OpenBLAS ddot
 // (kinematics.py:11,77).
-#define ACAS2D_PACKED_SHAPES(X) X(1, 1) X(3, 1) X(2, 1) X(2, 4) X(4, 2) X(2, 32) X(4, 16)
+#define ACAS2D_PACKED_SHAPES(X) X(1, 1) X(3, 1) X(2, 1) X(4, 1) X(2, 4) X(4, 2) X(4, 4) X(4, 8) X(2, 32) X(4, 16)
 namespace acas2d {
 constexpr bool kFast = false;
 }

@@ -163,18 +163,67 @@ __device__ __forceinline__ double m_copysign(double a, double b) { return copysi
 
 // hardware fast paths (FAST formulation; the double overloads keep FAST usable for T = double)
 __device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ double f_rcp(double x) { return 1.0 / x; }
+// float64 FAST: v_rcp_f64 seed + two Newton steps (1e-16 relative) instead of the full IEEE division sequence
+__device__ __forceinline__ double f_rcp(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    const double y1 = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    const double y2 = __builtin_fma(__builtin_fma(-x, y1, 1.0), y1, y1);
+    return (x != 0.0 && x - x == 0.0) ? y2 : y;          // 0, inf, NaN: the seed already is 1 / x
+}
 __device__ __forceinline__ float f_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double f_rsq(double x) { return 1.0 / sqrt(x); }
+// float64 FAST: v_rsq_f64 (a ~2^-26 seed) and two Newton steps y <- y (1.5 - 0.5 x y^2): ~12 instructions and
+// 1e-16 relative instead of a correctly rounded sqrt followed by a division (~45).  x = 0 -> inf, x = NaN -> NaN
+// as 1 / sqrt(x) gives them (the Newton steps are skipped where they would produce inf * 0).
+__device__ __forceinline__ double f_rsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    const double y1 = y * __builtin_fma(-hx * y, y, 1.5);
+    const double y2 = y1 * __builtin_fma(-hx * y1, y1, 1.5);
+    return (x > 0.0 && x < __builtin_inf()) ? y2 : y;
+}
 __device__ __forceinline__ float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ double f_sqrt(double x) { return sqrt(x); }
+// float64 FAST: sqrt(x) = x rsq(x) with one correction step (error below 1 ulp; libm's is correctly rounded at
+// three times the instructions).  0 -> 0, inf -> inf, negative / NaN -> NaN.
+__device__ __forceinline__ double f_rsq(double x);
+__device__ __forceinline__ double f_sqrt(double x) {
+    const double y = f_rsq(x), s = x * y;
+    const double r = __builtin_fma(__builtin_fma(-s, s, x), 0.5 * y, s);
+    return (x > 0.0 && x < __builtin_inf()) ? r : (x == 0.0 ? x : (x < 0.0 ? __builtin_nan("") : x));
+}
 // sin / cos of an angle given in REVOLUTIONS (v_sin_f32 / v_cos_f32 compute sin(2 pi x))
 __device__ __forceinline__ void f_sincos_rev(float r, float* s, float* c) {
     *s = __builtin_amdgcn_sinf(r);
     *c = __builtin_amdgcn_cosf(r);
 }
+// float64 FAST: headings are a fraction of a revolution away from [0, 1], so the quadrant comes off exactly
+// (4 r and the subtraction are exact) and what is left is |theta| <= pi/4, where the Taylor series to
+// theta^15 / theta^16 are below 5e-17 -- no Payne-Hanek path, no table, ~40 instructions instead of ocml's
+// full-range sincos.  Absolute error ~1e-16 (the reference's own argument (psi / 360) 2 pi carries 1e-15).
 __device__ __forceinline__ void f_sincos_rev(double r, double* s, double* c) {
-    sincos(r * 6.28318530717958647692, s, c);
+    const double q = __builtin_rint(r * 4.0);
+    const double t = __builtin_fma(r, 4.0, -q) * 1.57079632679489661923;
+    const double u = t * t;
+    double ps = -1.0 / 1307674368000.0;
+    ps = __builtin_fma(ps, u, 1.0 / 6227020800.0);
+    ps = __builtin_fma(ps, u, -1.0 / 39916800.0);
+    ps = __builtin_fma(ps, u, 1.0 / 362880.0);
+    ps = __builtin_fma(ps, u, -1.0 / 5040.0);
+    ps = __builtin_fma(ps, u, 1.0 / 120.0);
+    ps = __builtin_fma(ps, u, -1.0 / 6.0);
+    const double sn = __builtin_fma(t * u, ps, t);
+    double pc = 1.0 / 20922789888000.0;
+    pc = __builtin_fma(pc, u, -1.0 / 87178291200.0);
+    pc = __builtin_fma(pc, u, 1.0 / 479001600.0);
+    pc = __builtin_fma(pc, u, -1.0 / 3628800.0);
+    pc = __builtin_fma(pc, u, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, u, -1.0 / 720.0);
+    pc = __builtin_fma(pc, u, 1.0 / 24.0);
+    pc = __builtin_fma(pc, u, -0.5);
+    const double cs = __builtin_fma(u, pc, 1.0);
+    const int qi = (int)q;
+    const double ss = (qi & 1) ? cs : sn, cc = (qi & 1) ? sn : cs;    // sin / cos of theta + qi pi / 2
+    *s = (qi & 2) ? -ss : ss;
+    *c = ((qi + 1) & 2) ? -cc : cc;
 }
 
 template <typename T> struct Const;
@@ -216,9 +265,16 @@ __device__ __forceinline__ T wrap360_window(T a) {
     r = (a < T(0)) ? a + m : r;
     return r;
 }
+// The FAST formulation's wrap: the window alone in float32; the float64 build keeps the general form (its
+// rarely taken fmod branch costs nothing measurable there, and injected headings stay covered).
+template <typename T>
+__device__ __forceinline__ T wrap_fast(T a) {
+    if constexpr (sizeof(T) == 4) return wrap360_window(a);
+    else return py_mod360(a);
+}
 template <typename T, bool FAST>
 __device__ __forceinline__ T wrap360(T a) {
-    if constexpr (FAST) return wrap360_window(a);
+    if constexpr (FAST) return wrap_fast(a);
     else return py_mod360(a);
 }
 
@@ -483,7 +539,7 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
         f_sincos_rev(o.psi * Const<T>::inv360, &c.so, &c.co);
         T s1 = c.so, c1 = c.co;
         if constexpr (!ZERO_ACTION) {
-            T psi1 = wrap360_window(o.psi + (o.a_lat * f_rcp(o.v)) * p.dt);
+            T psi1 = wrap_fast(o.psi + (o.a_lat * f_rcp(o.v)) * p.dt);
             f_sincos_rev(psi1 * Const<T>::inv360, &s1, &c1);
         }
         const T vdt = o.v * p.dt;
@@ -491,7 +547,10 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
         c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
         const T gdx = o.gx - o.x, gdy = o.gy - o.y;
         c.d_goal = f_sqrt(m_fma(gdy, gdy, gdx * gdx));
-        c.h_goal = rounded(atan2_rev(gdy, gdx) * T(360));   // materialised: evaluate() subtracts it from psi
+        // materialised: evaluate() subtracts it from psi.  (float64: the degree-15 polynomial is a float32-grade
+        // 2.6e-8 rev; one libm atan2 per lane and step keeps the heading at 1e-13 degrees)
+        if constexpr (sizeof(T) == 4) c.h_goal = rounded(atan2_rev(gdy, gdx) * T(360));
+        else c.h_goal = relative_angle(o.x, o.y, o.gx, o.gy);
         c.d_dev = gdy;            // d_goal * sin(atan2(gdy, gdx)) == gdy          (game.py:175-180)
     } else {
         m_sincos(deg2rad_ref(o.psi), &c.so, &c.co);
@@ -1363,7 +1422,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // game.py:225 + aircraft.py:16-26 for the player
             o.a_lat = action * p.acc_lat_limit;
             if constexpr (FAST) {
-                o.psi = wrap360_window(o.psi + o.a_lat * f_rcp(o.v));   // (a_lat / (v dt)) dt
+                o.psi = wrap_fast(o.psi + o.a_lat * f_rcp(o.v));        // (a_lat / (v dt)) dt
                 T sn, cs;
                 f_sincos_rev(o.psi * Const<T>::inv360, &sn, &cs);
                 const T vdt = o.v * p.dt;

@@ -83,40 +83,40 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
     return ACAS2D_OK;
 }
 
-template <typename T, int C, int G, bool PACKED>
+template <typename T, bool FAST, int C, int G, bool PACKED>
 static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, const Params<T>& p,
                        const ResetParamsT<T>& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
                        int64_t env_offset, int64_t n_envs, int N) {
     if (auto_reset)
-        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, FAST, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
                            p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
     else
-        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, kFast, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, FAST, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
                            p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
 }
 
-template <typename T, int C, int G>
+template <typename T, bool FAST, int C, int G>
 static void rollout_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
                           const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
                           int64_t n_envs, int N, int n_steps) {
-    hipLaunchKernelGGL((step_kernel<T, C, G, true, true, kFast, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+    hipLaunchKernelGGL((step_kernel<T, C, G, true, true, FAST, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
                        p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, PolicyW{});
 }
 
 // the same with the SB3 actor evaluated in the kernel (thread-per-env shapes only)
-template <typename T, int C>
+template <typename T, bool FAST, int C>
 static void policy_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
                          const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
                          int64_t n_envs, int N, int n_steps, const PolicyW& pw) {
-    hipLaunchKernelGGL((step_kernel<T, C, 1, true, true, kFast, true, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+    hipLaunchKernelGGL((step_kernel<T, C, 1, true, true, FAST, true, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
                        p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, pw);
 }
 
-template <typename T, int C, int G, bool PACKED>
+template <typename T, bool FAST, int C, int G, bool PACKED>
 static void reset_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
                         const State<T>& s, const uint8_t* mask, T* obs, int do_init, uint32_t k0, uint32_t k1,
                         int64_t env_offset, int64_t n_envs, int N) {
-    hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, kFast>), dim3(g.grid), dim3(kBlock),
+    hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, FAST>), dim3(g.grid), dim3(kBlock),
                        g.lds_bytes, stream, p, rp, s, mask, obs, do_init, k0, k1, env_offset, n_envs, N, g.tile_elems);
 }
 
@@ -147,8 +147,8 @@ static int resolve_shape(int n_traffic, Shape* out) {
     return ACAS2D_OK;
 }
 
-template <typename T>
-int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_, uint32_t flags,
+template <typename T, bool FAST>
+static int launch_step_impl(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_, uint32_t flags,
                 uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
     if (!cfg || !io_) { set_error("acas2d_step: NULL cfg / io"); return ACAS2D_EINVAL; }
     if (!state_complete(st)) { set_error("acas2d_step: NULL state or a NULL state buffer"); return ACAS2D_EINVAL; }
@@ -169,22 +169,22 @@ int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStep
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const bool ar = (flags & ACAS2D_AUTO_RESET) != 0;
     if (sh.packed) {
-#define X(C_, G_) if (sh.C == C_ && sh.G == G_) step_shape<T, C_, G_, true>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic);
+#define X(C_, G_) if (sh.C == C_ && sh.G == G_) step_shape<T, FAST, C_, G_, true>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic);
         ACAS2D_PACKED_SHAPES(X)
 #undef X
     } else {
         switch (sh.G) {
-            case 1:  step_shape<T, 1, 1, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
-            case 4:  step_shape<T, 1, 4, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
-            case 16: step_shape<T, 1, 16, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
-            default: step_shape<T, 1, 64, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 1:  step_shape<T, FAST, 1, 1, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 4:  step_shape<T, FAST, 1, 4, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 16: step_shape<T, FAST, 1, 16, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
+            default: step_shape<T, FAST, 1, 64, false>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic); break;
         }
     }
     return check_launch("acas2d_step launch");
 }
 
-template <typename T>
-int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_, int32_t n_steps,
+template <typename T, bool FAST>
+static int launch_rollout_impl(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_, int32_t n_steps,
                    uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
     if (!cfg || !io_) { set_error("acas2d_rollout: NULL cfg / io"); return ACAS2D_EINVAL; }
     if (!state_complete(st)) { set_error("acas2d_rollout: NULL state or a NULL state buffer"); return ACAS2D_EINVAL; }
@@ -209,14 +209,14 @@ int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dS
     const StepIO<T> io{(const T*)io_->actions, (T*)io_->obs, (T*)io_->reward, io_->done, io_->outcome,
                        (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#define X(C_, G_) if (sh.C == C_ && sh.G == G_) rollout_shape<T, C_, G_>(g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, n_steps);
+#define X(C_, G_) if (sh.C == C_ && sh.G == G_) rollout_shape<T, FAST, C_, G_>(g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, n_steps);
     ACAS2D_PACKED_SHAPES(X)
 #undef X
     return check_launch("acas2d_rollout launch");
 }
 
-template <typename T>
-int launch_rollout_policy(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_,
+template <typename T, bool FAST>
+static int launch_rollout_policy_impl(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_,
                           const Acas2dPolicy* pol, const void* obs_in, int32_t n_steps, uint64_t seed,
                           int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
     if (!cfg || !io_ || !pol) { set_error("acas2d_rollout_policy: NULL cfg / io / policy"); return ACAS2D_EINVAL; }
@@ -248,14 +248,14 @@ int launch_rollout_policy(const Acas2dConfig* cfg, const Acas2dState* st, const 
     const PolicyW pw{(const float*)pol->w1t, (const float*)pol->b1, (const float*)pol->w2t, (const float*)pol->b2,
                      (const float*)pol->w3, (const float*)pol->b3, const_cast<void*>(io_->actions), obs_in};
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#define X(C_, G_) if constexpr (G_ == 1) { if (C_ == n_traffic) policy_shape<T, C_>(g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, n_steps, pw); }
+#define X(C_, G_) if constexpr (G_ == 1) { if (C_ == n_traffic) policy_shape<T, FAST, C_>(g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, n_steps, pw); }
     ACAS2D_PACKED_SHAPES(X)
 #undef X
     return check_launch("acas2d_rollout_policy launch");
 }
 
-template <typename T>
-int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* mask, void* obs,
+template <typename T, bool FAST>
+static int launch_reset_impl(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* mask, void* obs,
                  int32_t do_init, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,
                  hipStream_t stream) {
     if (!cfg) { set_error("acas2d_reset: NULL cfg"); return ACAS2D_EINVAL; }
@@ -273,18 +273,52 @@ int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* 
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     if (do_init < 0) { set_error("acas2d_reset: do_init = %d", do_init); return ACAS2D_EINVAL; }
     if (sh.packed) {
-#define X(C_, G_) if (sh.C == C_ && sh.G == G_) reset_shape<T, C_, G_, true>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic);
+#define X(C_, G_) if (sh.C == C_ && sh.G == G_) reset_shape<T, FAST, C_, G_, true>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic);
         ACAS2D_PACKED_SHAPES(X)
 #undef X
     } else {
         switch (sh.G) {
-            case 1:  reset_shape<T, 1, 1, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
-            case 4:  reset_shape<T, 1, 4, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
-            case 16: reset_shape<T, 1, 16, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
-            default: reset_shape<T, 1, 64, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 1:  reset_shape<T, FAST, 1, 1, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 4:  reset_shape<T, FAST, 1, 4, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            case 16: reset_shape<T, FAST, 1, 16, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
+            default: reset_shape<T, FAST, 1, 64, false>(g, stream, p, rp, s, mask, (T*)obs, do_init, k0, k1, env_offset, n_envs, n_traffic); break;
         }
     }
     return check_launch("acas2d_reset launch");
+}
+
+// Formulation: the element type's own -- FAST for float32, EXACT for float64 -- unless the
+// configuration asks for ACAS2D_MATH_FAST, which gives the float64 entry points the algebraic formulation in
+// float64 arithmetic (float32 has no other).  Chosen per call; nothing is cached between calls.
+template <typename T>
+static bool fast_math(const Acas2dConfig* cfg) { return kFast || (cfg && cfg->math == ACAS2D_MATH_FAST); }
+
+template <typename T>
+int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, uint32_t flags,
+                uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
+    return fast_math<T>(cfg) ? launch_step_impl<T, true>(cfg, st, io, flags, seed, env_offset, n_envs, n_traffic, stream)
+                             : launch_step_impl<T, kFast>(cfg, st, io, flags, seed, env_offset, n_envs, n_traffic, stream);
+}
+template <typename T>
+int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, int32_t n_steps,
+                   uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
+    return fast_math<T>(cfg) ? launch_rollout_impl<T, true>(cfg, st, io, n_steps, seed, env_offset, n_envs, n_traffic, stream)
+                             : launch_rollout_impl<T, kFast>(cfg, st, io, n_steps, seed, env_offset, n_envs, n_traffic, stream);
+}
+template <typename T>
+int launch_rollout_policy(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io,
+                          const Acas2dPolicy* pol, const void* obs_in, int32_t n_steps, uint64_t seed,
+                          int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
+    return fast_math<T>(cfg)
+               ? launch_rollout_policy_impl<T, true>(cfg, st, io, pol, obs_in, n_steps, seed, env_offset, n_envs, n_traffic, stream)
+               : launch_rollout_policy_impl<T, kFast>(cfg, st, io, pol, obs_in, n_steps, seed, env_offset, n_envs, n_traffic, stream);
+}
+template <typename T>
+int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* mask, void* obs,
+                 int32_t do_init, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,
+                 hipStream_t stream) {
+    return fast_math<T>(cfg) ? launch_reset_impl<T, true>(cfg, st, mask, obs, do_init, seed, env_offset, n_envs, n_traffic, stream)
+                             : launch_reset_impl<T, kFast>(cfg, st, mask, obs, do_init, seed, env_offset, n_envs, n_traffic, stream);
 }
 
 template <typename T>

@@ -50,6 +50,16 @@ extern "C" {
 /* step flags */
 #define ACAS2D_AUTO_RESET 1u /* SB3 VecEnv semantics: reset finished envs inside the step */
 
+/* Acas2dConfig.math.  The float32 entry points always run the FAST formulation (algebraically identical to
+ * the reference, fewer roundings, hardware transcendentals; 1e-5-grade observations).  The float64 entry points
+ * run  DEFAULT: the reference's operation order literally, with libm (agrees with the CPU reference to ~1e-13:
+ *               the parity mode);
+ *      FAST:    the FAST formulation in float64 arithmetic -- d_cpa and d_dev in their algebraic forms (no
+ *               atan2 / atan / sin per aircraft), reciprocal multiplications, a range-limited sincos -- within
+ *               1e-9 of the reference on every fixture (tests/test_gpu_parity.py), at more than twice the rate. */
+#define ACAS2D_MATH_DEFAULT 0
+#define ACAS2D_MATH_FAST 1
+
 /* outcome codes = settings.py:6 OUTCOME_NAMES */
 #define ACAS2D_OUTCOME_NONE 0
 #define ACAS2D_OUTCOME_GOAL 1
@@ -63,7 +73,7 @@ typedef struct Acas2dConfig {
     double dt;               /* 1 / FPS                          aircraft.py:18        */
     double acc_lat_limit;    /* ACC_LAT_LIMIT                    settings.py:42        */
     int32_t max_steps;       /* MAX_STEPS                        settings.py:9         */
-    int32_t _pad;
+    int32_t math;            /* ACAS2D_MATH_*: which formulation the float64 entry points run */
     double collision_dist;   /* 2 * COLLISION_RADIUS             game.py:187           */
     double goal_radius;      /* GOAL_RADIUS                      game.py:192           */
     double safe_distance;    /* SAFE_DISTANCE                    rewards.py:16         */

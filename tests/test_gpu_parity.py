@@ -36,12 +36,21 @@ def O(oracle_mod):
     return oracle_mod
 
 
+@pytest.fixture(params=("exact", "fast"))
+def math(request):
+    """The two formulations of the float64 build (include/acas2d.h, ACAS2D_MATH_*): the reference's operation
+    order with libm, and the float32 build's algebraic formulation in float64 arithmetic.  Both are held to the
+    same fixtures at the same 1e-9 (the contract asks 1e-5)."""
+    return request.param
+
+
 class GpuEngine:
     """The HIP path behind the OracleEnvs interface (numpy float64 views), see helpers.py."""
 
-    def __init__(self, g, E, N, dtype=None, auto_reset=False, seed=13, env_offset=0):
+    def __init__(self, g, E, N, dtype=None, auto_reset=False, seed=13, env_offset=0, math="exact"):
         self.v = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype or torch.float64,
-                                auto_reset=auto_reset, seed=seed, env_offset=env_offset)
+                                auto_reset=auto_reset, seed=seed, env_offset=env_offset,
+                                config=g.ACAS2DConfig(n_traffic=N, fast_math=(math == "fast")))
         self.E, self.N = E, N
 
     @staticmethod
@@ -90,14 +99,26 @@ def grazing(fx_obs, N, cfg, band):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N", (1, 3, 8, 64))
-def test_f64_edge_vectors(g, O, N):
+def test_f64_edge_vectors(g, O, N, math):
     fx = H.load("ref_edge_n%d.npz" % N)
     E = len(fx["action"])
-    env = GpuEngine(g, E, N)
+    env = GpuEngine(g, E, N, math=math)
     env.set_state(fx["own"], fx["trf"], fx["goal"], fx["steps"])
     obs, reward, done, outcome, _ = env.step(fx["action"])
     assert np.array_equal(np.isnan(obs), np.isnan(fx["obs"]))
-    np.testing.assert_allclose(obs, fx["obs"], rtol=0, atol=1e-9, equal_nan=True)
+    want = fx["obs"].copy()
+    if math == "fast":
+        # kinematics.py:47 takes arctan(v12y / v12x): d_cpa changes SIGN with the sign of v12x.  The hand-placed
+        # mirror-image headings make the reference's v12x an exact 0 (or +-1 ulp) -- a coin toss of libm's cos that
+        # no other sincos reproduces (the float32 tests exclude |v12x| < 0.02 for the same reason); the magnitude
+        # still has to match.
+        rad = lambda d: d / 360.0 * 2 * np.pi  # noqa: E731
+        v12x = (fx["own_out"][:, 3] * np.cos(rad(fx["own_out"][:, 2])))[:, None] - fx["trf_out"][..., 3] * np.cos(rad(fx["trf_out"][..., 2]))
+        coin = np.abs(v12x) < 1e-9
+        assert coin.sum() <= E // 4              # the hand-placed parallel / mirror-image cases (incl. the 0 / 0 ones)
+        flip = coin & (np.sign(obs[:, 6::3][:, :N]) != np.sign(want[:, 6::3][:, :N]))
+        want[:, 6::3][:, :N][flip] *= -1.0
+    np.testing.assert_allclose(obs, want, rtol=0, atol=1e-9, equal_nan=True)
     np.testing.assert_allclose(reward, fx["reward"], rtol=0, atol=1e-9, equal_nan=True)
     np.testing.assert_allclose(np.stack([env.own_x, env.own_y, env.own_psi, env.own_v], 1),
                                fx["own_out"], rtol=0, atol=1e-9)
@@ -112,10 +133,10 @@ def test_f64_edge_vectors(g, O, N):
 
 
 @pytest.mark.parametrize("N", (1, 3, 8, 64))
-def test_f64_reference_rollouts(g, N):
+def test_f64_reference_rollouts(g, N, math):
     fx = H.load("ref_rollout_n%d.npz" % N)
     n_ep = len(fx["ep_own"])
-    env = GpuEngine(g, n_ep, N)
+    env = GpuEngine(g, n_ep, N, math=math)
     env.set_state(fx["ep_own"], fx["ep_trf"], fx["ep_goal"], np.zeros(n_ep, np.int32))
     np.testing.assert_allclose(env.observe(), fx["ep_obs0"], rtol=0, atol=1e-9)
     res = H.replay_rollout(env, fx)
@@ -125,12 +146,12 @@ def test_f64_reference_rollouts(g, N):
     assert res["reward"] < 1e-9 and res["total_reward"] < 1e-8
 
 
-def test_f64_reference_csv_baseline(g):
+def test_f64_reference_csv_baseline(g, math):
     """The reference's own golden CSV replayed on the GPU (100 constant-action episodes)."""
     dg = H.load("csv_baseline_digest.npz")
     cfg = g.ACAS2DConfig(n_traffic=1)
     own, trf, goal = H.parity_reset_states(cfg, 13, 2, 100)
-    env = GpuEngine(g, 100, 1)
+    env = GpuEngine(g, 100, 1, math=math)
     env.set_state(own, trf, goal, np.zeros(100, np.int32))
     env.observe()
     out = H.replay_baseline(env, dg, own, trf)
@@ -360,11 +381,11 @@ def test_f32_full_episodes_vs_f64_oracle(g, O, N):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,E,T", ((3, 4096, 60), (8, 2048, 200), (64, 512, 40), (1, 256, 450), (100, 96, 12)))
-def test_f64_auto_reset_vs_oracle(g, O, N, E, T):
+def test_f64_auto_reset_vs_oracle(g, O, N, E, T, math):
     """VecEnv semantics and the device Philox reset against the oracle, env-for-env: same seed
     => same episodes, bit-exact reset states, terminal obs / returns / lengths, episode counters."""
     ref = O.OracleEnvs(E, N, seed=99, env_offset=1000, auto_reset=True)
-    env = GpuEngine(g, E, N, auto_reset=True, seed=99, env_offset=1000)
+    env = GpuEngine(g, E, N, auto_reset=True, seed=99, env_offset=1000, math=math)
     o_ref, o_gpu = ref.reset(), env.reset()
     for name in ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi", "trf_v"):
         assert np.array_equal(getattr(env, name), getattr(ref, name)), name     # reset: bit-exact
@@ -394,7 +415,8 @@ def _oracle_config_from(O, cfg):
     """OracleConfig carrying a NON-default product configuration (same field names)."""
     cc, oc = cfg.to_c(), O.OracleConfig()
     for name, _ in O.OracleConfig._fields_:
-        setattr(oc, name, getattr(cc, name))
+        if name != "_pad":                      # (the product's `math` selector: the oracle has one formulation)
+            setattr(oc, name, getattr(cc, name))
     return oc
 
 
@@ -537,15 +559,22 @@ def test_f32_reset_names_the_same_episodes(g, O):
         assert checked > 50
 
 
+def _dtype_and_config(g, dtype_name, N):
+    """"float64fast" = the float64 build's FAST formulation (ACAS2DConfig.fast_math)."""
+    fast = dtype_name == "float64fast"
+    return getattr(torch, "float64" if fast else dtype_name), g.ACAS2DConfig(n_traffic=N, fast_math=fast)
+
+
 @pytest.mark.parametrize("dtype_name,N,E,T", (("float32", 8, 4096, 160), ("float64", 8, 1024, 120), ("float32", 64, 512, 40),
-                                               ("float32", 3, 2048, 60), ("float32", 1, 640, 450), ("float64", 3, 333, 50)))
+                                               ("float32", 3, 2048, 60), ("float32", 1, 640, 450), ("float64", 3, 333, 50),
+                                               ("float64fast", 8, 1024, 120), ("float64fast", 3, 333, 50)))
 def test_rollout_equals_sequential_steps(g, dtype_name, N, E, T):
     """acas2d_rollout_* (T steps fused in one launch, state in registers) == T x acas2d_step_*,
     bit for bit: observations, rewards, masks, side channels and the final state."""
-    dtype = getattr(torch, dtype_name)
+    dtype, cfg = _dtype_and_config(g, dtype_name, N)
     dev = "cuda:0"
-    a = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=77, env_offset=5)
-    b = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=77, env_offset=5)
+    a = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=77, env_offset=5, config=cfg)
+    b = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=77, env_offset=5, config=cfg)
     a.reset()
     b.reset()
     gen = torch.Generator(device=dev).manual_seed(11)
@@ -579,20 +608,19 @@ def test_rollout_equals_sequential_steps(g, dtype_name, N, E, T):
         g.ACAS2DVecEnv(16, 5, device=dev, dtype=dtype).rollout(torch.zeros(2, 16, device=dev, dtype=dtype))
 
 
-@pytest.mark.parametrize("dtype_name", ("float32", "float64"))
+@pytest.mark.parametrize("dtype_name", ("float32", "float64", "float64fast"))
 def test_rollout_wraps_and_stores_injected_headings_like_steps(g, dtype_name):
     """aircraft.py:22 wraps a heading (psi % 360) on every step.  Headings injected outside [0, 360)
     are wrapped by the first step and written back; the fused rollout keeps the traffic's sin / cos
     in registers across steps and must still leave the same (wrapped) state behind."""
-    dtype = getattr(torch, dtype_name)
     E, N, T = 256, 8, 7
-    cfg = g.ACAS2DConfig(n_traffic=N)
+    dtype, cfg = _dtype_and_config(g, dtype_name, N)
     own, trf, goal = H.parity_reset_states(cfg, 99, 0, E)
     own[:, 2] += 360.0                       # 357..363 -> 717..723: inside the float32 window (-360, 720)
     own[:, 2] = np.minimum(own[:, 2], 719.0)
     trf[:, :, 2] += 360.0 * (np.arange(N)[None, :] % 2)
-    a = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=3)
-    b = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=3)
+    a = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=3, config=cfg)
+    b = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=3, config=cfg)
     for v in (a, b):
         v.set_state(own, trf, goal, np.zeros(E, np.int32), observe=False)
     gen = torch.Generator(device="cuda:0").manual_seed(2)
@@ -609,12 +637,13 @@ def test_rollout_wraps_and_stores_injected_headings_like_steps(g, dtype_name):
 @pytest.mark.parametrize("dtype_name,N,shapes", (
     ("float32", 8, ("4,2", "8,1", "2,4", "generic,4", "generic,1")),
     ("float32", 64, ("4,16", "8,8", "2,32", "generic,16", "generic,64")),
-    ("float64", 8, ("2,4", "4,2", "generic,4"))))
+    ("float64", 8, ("2,4", "4,2", "generic,4")),
+    ("float64fast", 8, ("2,4", "4,2", "generic,4"))))
 def test_results_do_not_depend_on_the_work_shape(g, dtype_name, N, shapes):
     """How the traffic of an env is spread over lanes (ACAS2D_SHAPE, a tuning knob) must not change a
     single bit: both builds compile with -ffp-contract=off, every variant runs the same IEEE
     operations per aircraft (packed float2 math included), and the reset RNG is keyed per entity."""
-    dtype = getattr(torch, dtype_name)
+    dtype, cfg = _dtype_and_config(g, dtype_name, N)
     E, T = 1536, 120
     gen = torch.Generator(device="cuda:0").manual_seed(4)
     actions = torch.rand(T, E, generator=gen, device="cuda:0", dtype=dtype) * 2 - 1
@@ -622,7 +651,7 @@ def test_results_do_not_depend_on_the_work_shape(g, dtype_name, N, shapes):
     try:
         for sh in shapes:
             os.environ["ACAS2D_SHAPE"] = sh
-            v = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=8)
+            v = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=8, config=cfg)
             assert g.native.launch_geometry(E, N, 4 if dtype == torch.float32 else 8)["lanes_per_env"] == int(sh.split(",")[1])
             got = [v.reset().clone()]
             dones = 0

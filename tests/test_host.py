@@ -103,7 +103,7 @@ def test_c_abi_argument_validation_needs_no_gpu(g):
     # headline config: 4 traffic per lane as one 16-byte vector, 2 lanes per env, 32 envs per wave
     assert g.native.launch_geometry(65536, 8) == {"lanes_per_env": 2, "traffic_per_lane": 4,
                                                   "block_threads": 256, "grid_blocks": 512}
-    assert g.native.launch_geometry(65536, 8, 8)["traffic_per_lane"] == 2         # float64: 2 per 16 B
+    assert g.native.launch_geometry(65536, 8, 8)["traffic_per_lane"] == 4         # float64: 4 per lane (2 x 16 B)
     assert g.native.launch_geometry(4096, 3)["lanes_per_env"] == 1
     assert g.native.launch_geometry(10, 1)["lanes_per_env"] == 1
     assert g.native.launch_geometry(65536, 64)["lanes_per_env"] == 16
