@@ -485,6 +485,19 @@ __device__ __forceinline__ double uniform(double a, double b, double u) {
 __device__ __forceinline__ float u01f(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 __device__ __forceinline__ float uniformf(float a, float b, float u) { return fmaf(b - a, u, a); }
 
+// ---- store policies -----------------------------------------------------------------------------------------
+// A plain store leaves its line dirty in the XCD's L2, and every dirty line is written back when the kernel ends
+// (L2s are not coherent across XCDs, so a kernel boundary flushes them) -- AFTER the last wave has finished, with
+// nothing left to overlap it.  Measured at 65 536 x 8, reset-free (tools/run_variants.sh, one box):
+//   observations (7.6 MB, never re-read on the device)   plain 7.1 us per launch   non-temporal 4.8
+//   + state (traffic x / y, per-env scalars: 5.9 MB)      non-temporal 4.7 - 4.9 (no gain: the NEXT launch re-reads
+//                                                         those lines, and the XCD-aware block map finds them in L2)
+//   everything write-through (sc1)                        4.3 -- but UNSAFE and therefore not used: the kernel's
+//       completion does not wait for write-through stores still in flight (with or without s_waitcnt vmcnt(0)
+//       before s_endpgm, agent or system scope), and a device-to-host copy right behind the launch read stale
+//       observation rows in one run out of four (tests/test_gpu_parity.py::test_full_size_f64_vs_oracle).
+// So: observations non-temporal, state plain.
+
 // ---- per-lane vector of C traffic values ---------------------------------------------------------
 template <typename T, int C>
 struct alignas((C * sizeof(T)) % 16 == 0 ? 16 : ((C * sizeof(T)) % 8 == 0 ? 8 : sizeof(T))) Vec {
@@ -813,13 +826,8 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
         // rollout: a wrapped heading waits in registers for the last step's store
         if (tc != nullptr) { tc->dirty |= psi_changed; psi_changed = tc->dirty; }
         if (move && store_traffic) {
-#if ACAS2D_OBS_STORE >= 2
-            store_chunk<T, C>(reinterpret_cast<V*>(s.trf_x + i0), tr.x);
-            store_chunk<T, C>(reinterpret_cast<V*>(s.trf_y + i0), tr.y);
-#else
             *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
             *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
-#endif
             if (psi_changed) {                                                  // injected headings >= 360 only
                 *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;
                 if (tc != nullptr) tc->dirty = false;
@@ -1155,23 +1163,15 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
 // Chunk c (16 bytes, or one value on the unaligned path) is always written by lane c % 64, so a
 // later flush_rows() of the same tile rewrites every address from the SAME work-item (program
 // order, no cross-lane store ordering assumed).
-// 16-byte store of an observation chunk.  ACAS2D_OBS_STORE selects the cache policy (tuning
-// knob): 0 plain, 1 non-temporal (streaming: obs is written once and never re-read here;
-// measured 8.11 -> 7.7 us per launch at 65 536 x 8 and +4 % at 4 M envs), 2 also the traffic block.
-#ifndef ACAS2D_OBS_STORE
-#define ACAS2D_OBS_STORE 1
-#endif
+// One 16-byte observation chunk out, non-temporal (see "store policies").
 template <typename T, int W>
 __device__ __forceinline__ void store_chunk(Vec<T, W>* dst, const Vec<T, W>& v) {
-#if ACAS2D_OBS_STORE >= 1
+    static_assert((W & (W - 1)) == 0, "a 3-vector type is padded to 4 elements");
     typedef T NV __attribute__((ext_vector_type(W)));
     NV x;
 #pragma unroll
     for (int k = 0; k < W; ++k) x[k] = v.v[k];
     __builtin_nontemporal_store(x, reinterpret_cast<NV*>(dst));
-#else
-    *dst = v;
-#endif
 }
 
 template <typename T>
@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                 if constexpr (!AUTO_RESET) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); }
             };
             Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
-                                                             ROLLOUT ? &trig : nullptr, before_traffic);
+                                                       ROLLOUT ? &trig : nullptr, before_traffic);
 
             // game.py:249-292 evaluate()
             T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             if (!active) oc = 0;                          // a padding lane never finishes anything
             if (j == 0 && active) {
                 io.reward[el] = rw;
-                io.done[el] = oc != 0;
+                io.done[el] = (uint8_t)(oc != 0);
                 io.outcome[el] = oc;
                 if constexpr (!HANDOFF) {
                     if (last && (oc == 0 || !AUTO_RESET)) {
