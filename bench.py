@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--traffic", type=int, default=8)
     ap.add_argument("--dtype", choices=("f32", "f64"), default="f32")
+    ap.add_argument("--fast-math", action="store_true",
+                    help="float64 only: the FAST formulation in float64 arithmetic (ACAS2DConfig.fast_math)")
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
                     help="replay the step launches from captured hipGraphs (default) or launch eagerly")
     ap.add_argument("--chunk", type=int, default=200, help="largest number of steps per captured graph")
@@ -309,7 +311,7 @@ def main():
         torch.cuda.set_device(dev_index)
         dev = torch.device("cuda", dev_index)
         g.sharding.init_process_group(args.backend)
-        env = make_env(g, E, N, dtype, dev, rank, args)
+        env = make_env(g, E, N, dtype, dev, rank, args, fast_math=args.fast_math and args.dtype == "f64")
         sync = torch.cuda.synchronize
 
     chunk = pick_chunk(K, args.chunk)
@@ -410,9 +412,10 @@ def main():
             out["roofline"] = None
         else:
             geo = g.native.launch_geometry(E, N, s)
-            out["config"] = {"workload": "%d envs x N_TRAFFIC=%d per GPU, %s, one step-kernel launch per step(), "
+            out["config"] = {"workload": "%d envs x N_TRAFFIC=%d per GPU, %s%s, one step-kernel launch per step(), "
                                          "auto-reset %s, random actions U(-1,1)%s"
-                                         % (E, N, args.dtype, "off" if args.no_auto_reset else "on", diag),
+                                         % (E, N, args.dtype, " (FAST formulation)" if args.fast_math and args.dtype == "f64" else "",
+                                            "off" if args.no_auto_reset else "on", diag),
                              "envs_per_gpu": E, "n_traffic": N, "launch": args.launch, "steps_per_graph": chunk,
                              "warmup_graph_replays": spin_replays,
                              "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"],

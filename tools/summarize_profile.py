@@ -25,7 +25,7 @@ def counter(name, E):
     vals = []
     for f in glob.glob(os.path.join(d, "pmc_%s_%d" % (name, E), "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "step_kernel" in r["Kernel_Name"] and "true, false, false>" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            if "step_kernel<float, 4, 2, true, true, true, false, false>" in r["Kernel_Name"] and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"]))
     vals = vals[len(vals) // 4:]
     return statistics.mean(vals) if vals else None
@@ -40,7 +40,7 @@ def alg_bytes(E):
 out = {"dir": os.path.basename(d)}
 ks = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if ks:
-    rows = [r for r in csv.DictReader(open(ks[0])) if "step_kernel" in r["Name"]]
+    rows = [r for r in csv.DictReader(open(ks[0])) if "step_kernel<float, 4, 2" in r["Name"]]
     rows.sort(key=lambda r: -int(r["Calls"]))          # per-step launches first, then the fused-rollout ones
     if rows:
         out["kernel_trace"] = {k: rows[0][k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")}
@@ -69,5 +69,28 @@ if cal[4194304]["FETCH_SIZE_KiB"]:
                                       "hbm_write_bytes_per_launch": wr_b,
                                       "hbm_bytes_per_launch": rd_b + wr_b,
                                       "algorithmic_bytes_per_launch": sum(alg_bytes(65536)) }
+# float64 builds: kernel-trace statistics and the SQ instruction mix per launch
+for m in ("exact", "fast"):
+    ks = glob.glob(os.path.join(d, "trace_f64_" + m, "**", "*kernel_stats.csv"), recursive=True)
+    rec = {}
+    if ks:
+        rows = [r for r in csv.DictReader(open(ks[0])) if "step_kernel<double" in r["Name"]]
+        rows.sort(key=lambda r: -int(r["Calls"]))
+        if rows:
+            rec["kernel_trace"] = {k: rows[0][k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")}
+    try:
+        j = json.loads([l for l in open(os.path.join(d, "bench_f64_%s.json" % m)) if l.startswith("{")][-1])
+        rec["bench_traced"] = {"value": j["value"], "launch_us": j["roofline"]["launch_us"], "frac": j["roofline"]["frac"]}
+    except Exception as e:  # noqa: BLE001
+        rec["bench_traced"] = str(e)
+    out["f64_" + m] = rec
+for tag in ("f32", "f64_exact", "f64_fast"):
+    agg = {}
+    for f in glob.glob(os.path.join(d, "pmc_sq_" + tag, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "step_kernel" in r["Kernel_Name"]:
+                agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if agg:
+        out["sq_counters_per_launch_" + tag] = {k: statistics.mean(v[len(v) // 4:]) for k, v in sorted(agg.items())}
 print(json.dumps(out, indent=1))
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
