@@ -495,7 +495,7 @@ __device__ __forceinline__ float uniformf(float a, float b, float u) { return fm
 //   everything write-through (sc1)                        4.3 -- but UNSAFE and therefore not used: the kernel's
 //       completion does not wait for write-through stores still in flight (with or without s_waitcnt vmcnt(0)
 //       before s_endpgm, agent or system scope), and a device-to-host copy right behind the launch read stale
-//       observation rows in one run out of four (tests/test_gpu_parity.py::test_full_size_f64_vs_oracle).
+//       observation rows in one run out of four (the full-size float64 parity test of tests/test_gpu_parity.py).
 // So: observations non-temporal, state plain.
 
 // ---- per-lane vector of C traffic values ---------------------------------------------------------
