@@ -72,3 +72,23 @@ def test_pick_chunk_and_repeats():
     assert bench.pick_chunk(1009, 200) == 200            # a prime: whole replays + an eager remainder
     a = bench.parse(["--steps", "20"])
     assert a.steps == 20 and a.repeats == 0 and a.gpus == 1
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_real_ranks_on_one_gpu():
+    """The N > 1 path on hardware, as far as one GPU goes: `python bench.py --gpus 2` starts two ranks that both use
+    GPU 0 (--device 0, gloo for the barrier / MAX: RCCL wants one device per rank), each steps its own shard of
+    65 536 envs with its own global env offset, rank 0 prints the one line.  (The 8-GPU curve is the driver's.)"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--device", "0", "--steps", "100",
+                        "--warmup", "20", "--no-rollout"], capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["envs_per_gpu"] == 65536
+    # two ranks time-share one GPU: the whole-job rate is about the single-rank rate, never twice it
+    assert 4e9 < j["value"] < 2.4e10 and j["config"]["episodes_finished"] > 1000
+    assert "x2" in j["config"]["parallelism"] and j["roofline"]["frac"] > 0.15
