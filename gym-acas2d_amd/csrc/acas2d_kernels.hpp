@@ -490,8 +490,7 @@ __device__ __forceinline__ float uniformf(float a, float b, float u) { return fm
 // (L2s are not coherent across XCDs, so a kernel boundary flushes them) -- AFTER the last wave has finished, with
 // nothing left to overlap it.  Measured at 65 536 x 8, reset-free (tools/run_variants.sh, one box):
 //   observations (7.6 MB, never re-read on the device)   plain 7.1 us per launch   non-temporal 4.8
-//   + state (traffic x / y, per-env scalars: 5.9 MB)      non-temporal 4.7 - 4.9 (no gain: the NEXT launch re-reads
-//                                                         those lines, and the XCD-aware block map finds them in L2)
+//   + state (traffic x / y, per-env scalars: 5.9 MB)      non-temporal 4.7 - 4.9 (no gain)
 //   everything write-through (sc1)                        4.3 -- but UNSAFE and therefore not used: the kernel's
 //       completion does not wait for write-through stores still in flight (with or without s_waitcnt vmcnt(0)
 //       before s_endpgm, agent or system scope), and a device-to-host copy right behind the launch read stale
