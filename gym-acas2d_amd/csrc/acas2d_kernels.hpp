@@ -793,31 +793,14 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
 #pragma unroll
                 for (int k = 0; k < C; ++k) { st[k] = tc->st[k]; ct[k] = tc->ct[k]; }
             } else {
-                // Traffic flies straight, so its headings are already in [0, 360) after an episode's first step (and
-                // the reset draws them there): the wrap (aircraft.py:22) is the identity for the whole wave except in
-                // the step after headings were injected from outside.  One unsigned compare per heading finds that
-                // out -- as bit patterns exactly the floats in [+0, 360) are below 360.0f's (negative values, -0, NaN
-                // and anything >= 360 are not) -- and a wave-uniform branch skips six wrap instructions per heading.
-                bool in_range = true;
 #pragma unroll
-                for (int k = 0; k < C; ++k) in_range &= __float_as_uint(tr.psi.v[k]) < 0x43B40000u;
-                if (__builtin_expect(__ballot(!in_range) == 0ull, 1)) {
-#pragma unroll
-                    for (int k = 0; k < C; k += 2) {
-                        const F2 r = F2{tr.psi.v[k], tr.psi.v[k + 1]} * Const<float>::inv360;
-                        st[k] = __builtin_amdgcn_sinf(r.x); st[k + 1] = __builtin_amdgcn_sinf(r.y);
-                        ct[k] = __builtin_amdgcn_cosf(r.x); ct[k + 1] = __builtin_amdgcn_cosf(r.y);
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < C; k += 2) {
-                        F2 ps{tr.psi.v[k], tr.psi.v[k + 1]}, s2, c2;
-                        const F2 ps_in = ps;
-                        traffic_trig2(ps, s2, c2);
-                        tr.psi.v[k] = ps.x; tr.psi.v[k + 1] = ps.y;
-                        st[k] = s2.x; st[k + 1] = s2.y; ct[k] = c2.x; ct[k + 1] = c2.y;
-                        psi_changed |= (ps.x != ps_in.x) | (ps.y != ps_in.y);
-                    }
+                for (int k = 0; k < C; k += 2) {
+                    F2 ps{tr.psi.v[k], tr.psi.v[k + 1]}, s2, c2;
+                    const F2 ps_in = ps;
+                    traffic_trig2(ps, s2, c2);
+                    tr.psi.v[k] = ps.x; tr.psi.v[k + 1] = ps.y;
+                    st[k] = s2.x; st[k + 1] = s2.y; ct[k] = c2.x; ct[k + 1] = c2.y;
+                    psi_changed |= (ps.x != ps_in.x) | (ps.y != ps_in.y);
                 }
                 if (tc != nullptr) {
 #pragma unroll
