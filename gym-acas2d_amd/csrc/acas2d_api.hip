@@ -76,6 +76,16 @@ int acas2d_rollout_policy_f64(const Acas2dConfig* cfg, const Acas2dState* state,
                               int64_t env_offset, int64_t n_envs, int32_t n_traffic, void* stream) {
     return launch_rollout_policy<double>(cfg, state, io, policy, obs_in, n_steps, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
 }
+int acas2d_collect_f32(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dStepIO* io, const Acas2dActorCritic* ac,
+                       const void* obs_in, int32_t n_steps, uint64_t seed, int64_t env_offset, int64_t n_envs,
+                       int32_t n_traffic, void* stream) {
+    return launch_collect<float>(cfg, state, io, ac, obs_in, n_steps, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
+}
+int acas2d_collect_f64(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dStepIO* io, const Acas2dActorCritic* ac,
+                       const void* obs_in, int32_t n_steps, uint64_t seed, int64_t env_offset, int64_t n_envs,
+                       int32_t n_traffic, void* stream) {
+    return launch_collect<double>(cfg, state, io, ac, obs_in, n_steps, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
+}
 int acas2d_reset_f32(const Acas2dConfig* cfg, const Acas2dState* state, const uint8_t* mask, void* obs,
                      int32_t do_init, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,
                      void* stream) {

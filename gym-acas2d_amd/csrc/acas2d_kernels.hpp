@@ -1245,9 +1245,15 @@ __device__ __forceinline__ void flush_rows(const T* __restrict__ tile, T* __rest
 // input's 64 outgoing weights are contiguous.  float32 math in both builds (the reference's
 // policy.predict() runs its float32 torch module on float32-cast observations).
 struct PolicyW {
-    const float *w1t, *b1, *w2t, *b2, *w3, *b3;      // [D][64], [64], [64][64], [64], [64], [1]
+    const float *w1t, *b1, *w2t, *b2, *w3, *b3;      // actor: [D][64], [64], [64][64], [64], [64], [1]
     void* actions_out;                               // T[n_steps][E]: the action each step took
     const void* obs_in;                              // T[E][D]: the observation the first action is taken on
+    // SAMPLE (the collector of a PPO iteration, SB3 collect_rollouts): the value net (same layout), the
+    // state-independent log-std, per-step value / log-probability outputs, the key and step of the noise stream
+    const float *v1t, *vb1, *v2t, *vb2, *v3, *vb3;
+    const float* log_std;                            // [1]
+    void *values_out, *logp_out;                     // T[n_steps][E]
+    uint32_t nk0, nk1, noise_step;
 };
 constexpr int kPolicyHidden = 64;
 
@@ -1258,15 +1264,18 @@ __device__ __forceinline__ float tanh_hw(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// One SB3 MlpPolicy head, obs -> Linear(D,64) tanh -> Linear(64,64) tanh -> Linear(64,1): the actor's mean or the
+// critic's value, by the weights handed in.
 template <int D>
-__device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&x)[D]) {
+__device__ __forceinline__ float policy_mlp(const float* w1t_, const float* b1_, const float* w2t_, const float* b2_,
+                                            const float* w3_, const float* b3_, const float (&x)[D]) {
     constexpr int H2 = kPolicyHidden / 2;
-    const F2 ACAS2D_AS4* w1 = (const F2 ACAS2D_AS4*)pw.w1t;
-    const F2 ACAS2D_AS4* b1 = (const F2 ACAS2D_AS4*)pw.b1;
-    const F2 ACAS2D_AS4* w2 = (const F2 ACAS2D_AS4*)pw.w2t;
-    const F2 ACAS2D_AS4* b2 = (const F2 ACAS2D_AS4*)pw.b2;
-    const F2 ACAS2D_AS4* w3 = (const F2 ACAS2D_AS4*)pw.w3;
-    const float ACAS2D_AS4* b3 = (const float ACAS2D_AS4*)pw.b3;
+    const F2 ACAS2D_AS4* w1 = (const F2 ACAS2D_AS4*)w1t_;
+    const F2 ACAS2D_AS4* b1 = (const F2 ACAS2D_AS4*)b1_;
+    const F2 ACAS2D_AS4* w2 = (const F2 ACAS2D_AS4*)w2t_;
+    const F2 ACAS2D_AS4* b2 = (const F2 ACAS2D_AS4*)b2_;
+    const F2 ACAS2D_AS4* w3 = (const F2 ACAS2D_AS4*)w3_;
+    const float ACAS2D_AS4* b3 = (const float ACAS2D_AS4*)b3_;
     F2 h[H2], g[H2];
 #pragma unroll
     for (int i = 0; i < H2; ++i) h[i] = b1[i];
@@ -1288,8 +1297,12 @@ __device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&
     F2 acc = F2{0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < H2; ++i) acc = __builtin_elementwise_fma(w3[i], F2{tanh_hw(g[i].x), tanh_hw(g[i].y)}, acc);
-    const float a = (acc.x + acc.y) + b3[0];
-    return fminf(fmaxf(a, -1.0f), 1.0f);
+    return (acc.x + acc.y) + b3[0];
+}
+// the deterministic action = clip(mean, -1, 1) (SB3 policies.py predict())
+template <int D>
+__device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&x)[D]) {
+    return fminf(fmaxf(policy_mlp<D>(pw.w1t, pw.b1, pw.w2t, pw.b2, pw.w3, pw.b3, x), -1.0f), 1.0f);
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------
@@ -1300,13 +1313,19 @@ __device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&
 // arithmetic is this same code, so rollout(T) == T x step() bit for bit.
 // With POLICY (rollout, one lane per env) the action of every step comes from policy_action() on the
 // previous observation instead of from actions[t][E], which becomes an output.
-template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false>
+// With SAMPLE on top (the collector of a PPO iteration, SB3's collect_rollouts) the action is drawn: mean + exp(log_std)
+// eps, eps ~ N(0, 1) from a Philox block per env and step (Box-Muller); the raw action, the critic's value of the
+// observation and the log-probability of the draw are stored per step, the env is stepped with the clipped action, and
+// a non-finite observation entry reaches the networks as 0 (the reference's NaN d_cpa in exact parallel flight).
+template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false,
+          bool SAMPLE = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
                                                       int tile_elems, int n_steps, PolicyW pw) {
     static_assert(!ROLLOUT || (AUTO_RESET && PACKED), "rollout: auto-reset semantics, packed shapes");
     static_assert(!POLICY || (ROLLOUT && G == 1), "in-kernel policy: rollout mode, one lane per env");
+    static_assert(!SAMPLE || POLICY, "sampling needs the in-kernel policy");
     constexpr int NS = PACKED ? C * G : 0;         // packed shapes: n_traffic is a compile-time constant
     const int N = PACKED ? NS : N_arg;
     constexpr int EPW = 64 / G;                    // envs per wavefront
@@ -1410,8 +1429,33 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             // pointers through an empty asm makes the loads depend on the iteration.
             PolicyW pw_t = pw;
             asm volatile("" : "+s"(pw_t.w1t), "+s"(pw_t.b1), "+s"(pw_t.w2t), "+s"(pw_t.b2), "+s"(pw_t.w3), "+s"(pw_t.b3));
-            action = (T)policy_action<DP>(pw_t, x);
-            if (active) (static_cast<T*>(pw.actions_out) + e_wave + te)[el] = action;
+            if constexpr (SAMPLE) {
+#pragma unroll
+                for (int i = 0; i < DP; ++i) x[i] = (x[i] == x[i] && fabsf(x[i]) < __builtin_inff()) ? x[i] : 0.0f;
+                const float mean = policy_mlp<DP>(pw_t.w1t, pw_t.b1, pw_t.w2t, pw_t.b2, pw_t.w3, pw_t.b3, x);
+                asm volatile("" : "+s"(pw_t.v1t), "+s"(pw_t.vb1), "+s"(pw_t.v2t), "+s"(pw_t.vb2), "+s"(pw_t.v3), "+s"(pw_t.vb3),
+                                  "+s"(pw_t.log_std));
+                const float value = policy_mlp<DP>(pw_t.v1t, pw_t.vb1, pw_t.v2t, pw_t.vb2, pw_t.v3, pw_t.vb3, x);
+                const float log_std = ((const float ACAS2D_AS4*)pw_t.log_std)[0];
+                // eps ~ N(0, 1): one Philox block per (global env, noise step + t), Box-Muller on two 24-bit uniforms
+                const uint64_t gid = (uint64_t)(env_offset + e_wave + el);
+                const U4 w = philox4x32_10(U4{(uint32_t)gid, (uint32_t)(gid >> 32), pw.noise_step + (uint32_t)t, 0x6e6f6973u},
+                                           pw.nk0, pw.nk1);
+                const float u1 = u01f(w.x), u2 = u01f(w.y);
+                const float eps = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) *    // -2 ln u1
+                                  __builtin_amdgcn_cosf(u2);                                                    // cos(2 pi u2)
+                const float raw = fmaf(__builtin_amdgcn_exp2f(log_std * 1.4426950408889634f), eps, mean);
+                const float logp = fmaf(-0.5f * eps, eps, -log_std) - 0.9189385332046727f;                      // - log sqrt(2 pi)
+                if (active) {
+                    (static_cast<T*>(pw.actions_out) + e_wave + te)[el] = (T)raw;      // the buffer keeps the RAW action,
+                    (static_cast<T*>(pw.values_out) + e_wave + te)[el] = (T)value;     // the env sees the clipped one
+                    (static_cast<T*>(pw.logp_out) + e_wave + te)[el] = (T)logp;
+                }
+                action = (T)fminf(fmaxf(raw, -1.0f), 1.0f);
+            } else {
+                action = (T)policy_action<DP>(pw_t, x);
+                if (active) (static_cast<T*>(pw.actions_out) + e_wave + te)[el] = action;
+            }
         } else {
             if (ROLLOUT && active && t + 1 < T_steps) action_next = io.actions[n_envs + el];
         }
@@ -1666,6 +1710,10 @@ template <typename T>
 int launch_rollout_policy(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io,
                           const Acas2dPolicy* pol, const void* obs_in, int32_t n_steps, uint64_t seed,
                           int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream);
+template <typename T>
+int launch_collect(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, const Acas2dActorCritic* ac,
+                   const void* obs_in, int32_t n_steps, uint64_t seed, int64_t env_offset, int64_t n_envs,
+                   int32_t n_traffic, hipStream_t stream);
 template <typename T>
 int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* mask, void* obs,
                  int32_t do_init, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,

@@ -107,9 +107,13 @@ static void rollout_shape(const Geometry& g, hipStream_t stream, const Params<T>
 template <typename T, bool FAST, int C>
 static void policy_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
                          const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
-                         int64_t n_envs, int N, int n_steps, const PolicyW& pw) {
-    hipLaunchKernelGGL((step_kernel<T, C, 1, true, true, FAST, true, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, pw);
+                         int64_t n_envs, int N, int n_steps, const PolicyW& pw, bool sample) {
+    if (sample)
+        hipLaunchKernelGGL((step_kernel<T, C, 1, true, true, FAST, true, true, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes,
+                           stream, p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, pw);
+    else
+        hipLaunchKernelGGL((step_kernel<T, C, 1, true, true, FAST, true, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes,
+                           stream, p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, pw);
 }
 
 template <typename T, bool FAST, int C, int G, bool PACKED>
@@ -218,7 +222,8 @@ static int launch_rollout_impl(const Acas2dConfig* cfg, const Acas2dState* st, c
 template <typename T, bool FAST>
 static int launch_rollout_policy_impl(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_,
                           const Acas2dPolicy* pol, const void* obs_in, int32_t n_steps, uint64_t seed,
-                          int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
+                          int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream,
+                          const Acas2dActorCritic* ac = nullptr) {
     if (!cfg || !io_ || !pol) { set_error("acas2d_rollout_policy: NULL cfg / io / policy"); return ACAS2D_EINVAL; }
     if (!state_complete(st)) { set_error("acas2d_rollout_policy: NULL state or a NULL state buffer"); return ACAS2D_EINVAL; }
     if (!io_->actions || !io_->obs || !io_->reward || !io_->done || !io_->outcome || !obs_in) {
@@ -245,10 +250,19 @@ static int launch_rollout_policy_impl(const Acas2dConfig* cfg, const Acas2dState
     const State<T> s = make_state<T>(*st);
     const StepIO<T> io{(const T*)io_->actions, (T*)io_->obs, (T*)io_->reward, io_->done, io_->outcome,
                        (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
-    const PolicyW pw{(const float*)pol->w1t, (const float*)pol->b1, (const float*)pol->w2t, (const float*)pol->b2,
-                     (const float*)pol->w3, (const float*)pol->b3, const_cast<void*>(io_->actions), obs_in};
+    PolicyW pw{(const float*)pol->w1t, (const float*)pol->b1, (const float*)pol->w2t, (const float*)pol->b2,
+               (const float*)pol->w3, (const float*)pol->b3, const_cast<void*>(io_->actions), obs_in,
+               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    if (ac) {
+        if (!ac->v1t || !ac->vb1 || !ac->v2t || !ac->vb2 || !ac->v3 || !ac->vb3 || !ac->log_std || !ac->values || !ac->logp) {
+            set_error("acas2d_collect: the value net, log_std, values and logp are required"); return ACAS2D_EINVAL; }
+        pw.v1t = (const float*)ac->v1t; pw.vb1 = (const float*)ac->vb1; pw.v2t = (const float*)ac->v2t;
+        pw.vb2 = (const float*)ac->vb2; pw.v3 = (const float*)ac->v3; pw.vb3 = (const float*)ac->vb3;
+        pw.log_std = (const float*)ac->log_std; pw.values_out = ac->values; pw.logp_out = ac->logp;
+        pw.nk0 = (uint32_t)ac->noise_seed; pw.nk1 = (uint32_t)(ac->noise_seed >> 32); pw.noise_step = ac->noise_step;
+    }
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#define X(C_, G_) if constexpr (G_ == 1) { if (C_ == n_traffic) policy_shape<T, FAST, C_>(g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, n_steps, pw); }
+#define X(C_, G_) if constexpr (G_ == 1) { if (C_ == n_traffic) policy_shape<T, FAST, C_>(g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic, n_steps, pw, ac != nullptr); }
     ACAS2D_PACKED_SHAPES(X)
 #undef X
     return check_launch("acas2d_rollout_policy launch");
@@ -312,6 +326,15 @@ int launch_rollout_policy(const Acas2dConfig* cfg, const Acas2dState* st, const 
     return fast_math<T>(cfg)
                ? launch_rollout_policy_impl<T, true>(cfg, st, io, pol, obs_in, n_steps, seed, env_offset, n_envs, n_traffic, stream)
                : launch_rollout_policy_impl<T, kFast>(cfg, st, io, pol, obs_in, n_steps, seed, env_offset, n_envs, n_traffic, stream);
+}
+template <typename T>
+int launch_collect(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, const Acas2dActorCritic* ac,
+                   const void* obs_in, int32_t n_steps, uint64_t seed, int64_t env_offset, int64_t n_envs,
+                   int32_t n_traffic, hipStream_t stream) {
+    if (!ac) { set_error("acas2d_collect: NULL actor-critic"); return ACAS2D_EINVAL; }
+    return fast_math<T>(cfg)
+               ? launch_rollout_policy_impl<T, true>(cfg, st, io, &ac->actor, obs_in, n_steps, seed, env_offset, n_envs, n_traffic, stream, ac)
+               : launch_rollout_policy_impl<T, kFast>(cfg, st, io, &ac->actor, obs_in, n_steps, seed, env_offset, n_envs, n_traffic, stream, ac);
 }
 template <typename T>
 int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* mask, void* obs,

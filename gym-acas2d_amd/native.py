@@ -8,7 +8,7 @@ from .config import CConfig
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libacas2d_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 AUTO_RESET = 1
 
@@ -30,9 +30,17 @@ class CPolicy(C.Structure):
                [("hidden", C.c_int32), ("_pad", C.c_int32)]
 
 
+class CActorCritic(C.Structure):
+    """struct Acas2dActorCritic: actor + value net + log-std, the per-step value / log-prob outputs, the noise stream."""
+    _fields_ = [("actor", CPolicy)] + [(n, C.c_void_p) for n in ("v1t", "vb1", "v2t", "vb2", "v3", "vb3", "log_std",
+                                                                 "values", "logp")] + \
+               [("noise_seed", C.c_uint64), ("noise_step", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 EXPORTS = ("acas2d_abi_version", "acas2d_config_size", "acas2d_state_size", "acas2d_last_error", "acas2d_step_f32",
            "acas2d_step_f64", "acas2d_rollout_f32", "acas2d_rollout_f64", "acas2d_rollout_policy_f32",
-           "acas2d_rollout_policy_f64", "acas2d_reset_f32", "acas2d_reset_f64", "acas2d_launch_geometry")
+           "acas2d_rollout_policy_f64", "acas2d_collect_f32", "acas2d_collect_f64", "acas2d_reset_f32", "acas2d_reset_f64",
+           "acas2d_launch_geometry")
 
 
 class NativeLibraryError(RuntimeError):
@@ -88,6 +96,11 @@ def lib():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.POINTER(CStepIO), C.POINTER(CPolicy), C.c_void_p,
+                      C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+    for name in ("acas2d_collect_f32", "acas2d_collect_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.POINTER(CStepIO), C.POINTER(CActorCritic), C.c_void_p,
                       C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
     for name in ("acas2d_reset_f32", "acas2d_reset_f64"):
         f = getattr(L, name)

@@ -149,13 +149,22 @@ def ppo_loss(policy, cfg, obs, act, old_logp, adv, ret):
 
 
 class PPOTrainer:
-    def __init__(self, venv, config=None, policy=None, use_graphs=None):
+    """collector: "graphs" (default on a GPU: one captured env step replayed n_steps times), "fused" (the whole
+    collection of an iteration in ONE hand-written launch, ACAS2DVecEnv.collect(): actor, critic, Gaussian sampling
+    and the env step inside the kernel; its noise comes from the kernel's own Philox stream instead of torch's
+    generator) or "eager" (op by op).  The update always runs from the captured graphs when `use_graphs`."""
+
+    def __init__(self, venv, config=None, policy=None, use_graphs=None, collector=None):
         self.venv = venv
         self.cfg = config or PPOConfig()
         torch.manual_seed(self.cfg.seed)
         self.device = venv.device
         self.policy = (policy or ActorCritic(venv.obs_dim)).to(self.device)
         self.use_graphs = (torch.device(self.device).type == "cuda") if use_graphs is None else bool(use_graphs)
+        self.collector = collector or ("graphs" if self.use_graphs else "eager")
+        if self.collector not in ("graphs", "fused", "eager") or (self.collector != "eager" and not self.use_graphs):
+            raise ValueError("collector %r needs use_graphs" % (self.collector,))
+        self._fused_out = None
         # (fused: one multi-tensor kernel for the 13 parameter tensors instead of ~10 foreach launches)
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5,
                                     capturable=self.use_graphs, **({"fused": True} if self.use_graphs else {}))
@@ -289,9 +298,28 @@ class PPOTrainer:
         if self.use_graphs:
             if self._graphs is None:
                 self._capture()
-            self.t_idx.zero_()
-            for _ in range(T):
-                self._graphs[0].replay()
+            if self.collector == "fused":
+                # one launch: rows t = 0 .. T-1 of the static buffers, then the captured GAE as usual
+                out = self.venv.collect(self.policy, T, noise_seed=cfg.seed, noise_step=self.num_timesteps // E,
+                                        out=self._fused_out)
+                self._fused_out = out
+                obs_all, rew = out["obs"].to(torch.float32), out["reward"].to(torch.float32)
+                self.nan_events.add_(torch.isnan(rew).sum() + torch.isnan(obs_all[1:]).any(-1).sum())
+                obs_all = torch.nan_to_num(obs_all, nan=0.0, posinf=0.0, neginf=0.0)    # what the kernel fed the networks
+                self.b_obs.copy_(obs_all[:T])
+                self.obs.copy_(obs_all[T])
+                self.b_act.copy_(out["actions"].to(torch.float32).unsqueeze(-1))
+                self.b_val.copy_(out["values"].to(torch.float32))
+                self.b_logp.copy_(out["logp"].to(torch.float32))
+                self.b_rew.copy_(torch.nan_to_num(rew, nan=0.0))
+                self.b_done.copy_(out["done"])
+                self.b_epret.copy_(out["episode_return"].to(torch.float32))
+                self.b_eplen.copy_(out["episode_steps"])
+                self.b_outcome.copy_(out["outcome"])
+            else:
+                self.t_idx.zero_()
+                for _ in range(T):
+                    self._graphs[0].replay()
             self._graphs[1].replay()
             done = self.b_done
             if bool(done.any()):                          # the iteration's one host synchronisation

@@ -342,6 +342,50 @@ class ACAS2DVecEnv:
         out["_weights"] = keep       # keep the transposed copies alive until the launch ran
         return out
 
+    def collect(self, policy, n_steps, noise_seed=0, noise_step=0, out=None):
+        """The collector of one PPO iteration in ONE kernel launch (acas2d_collect_*; SB3 `collect_rollouts` as
+        training_main.py:44-52 runs it): for n_steps steps draw `a ~ N(actor(obs), exp(log_std))`, record the raw
+        action, `critic(obs)` and the draw's log-probability, step the env with `clip(a, -1, 1)`.  `policy` is a
+        `ppo.ActorCritic` (SB3 MlpPolicy layout).  Starts from `self.outputs["obs"]` (call reset() / step() first).
+        Returns a dict of device tensors: obs [T + 1, E, D] (obs[t] is what action t was drawn on, obs[T] the
+        observation the next iteration starts from), actions / values / logp / reward [T, E], done [T, E] bool,
+        outcome, episode_return, episode_steps [T, E].  The noise stream depends on (noise_seed, global env index,
+        noise_step + t) only.  One lane per env: n_traffic in {1, 2, 3, 4, 8} (float32), {1, 2, 3, 4} (float64)."""
+        if not self.auto_reset:
+            raise RuntimeError("collect() has VecEnv auto-reset semantics; construct with auto_reset=True")
+        T, E, D, dev = int(n_steps), self.num_envs, self.obs_dim, self.device
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)  # noqa: E731
+        pn, vn = policy.mlp_extractor.policy_net, policy.mlp_extractor.value_net
+        keep = [f32(pn[0].weight).t().contiguous(), f32(pn[0].bias).contiguous(), f32(pn[2].weight).t().contiguous(),
+                f32(pn[2].bias).contiguous(), f32(policy.action_net.weight).reshape(-1).contiguous(),
+                f32(policy.action_net.bias).reshape(-1).contiguous(),
+                f32(vn[0].weight).t().contiguous(), f32(vn[0].bias).contiguous(), f32(vn[2].weight).t().contiguous(),
+                f32(vn[2].bias).contiguous(), f32(policy.value_net.weight).reshape(-1).contiguous(),
+                f32(policy.value_net.bias).reshape(-1).contiguous(), f32(policy.log_std).reshape(-1).contiguous()]
+        if keep[0].shape != (D, 64) or keep[2].shape != (64, 64) or keep[4].numel() != 64:
+            raise ValueError("policy must be the SB3 MlpPolicy actor-critic %d -> 64 -> 64 -> 1" % D)
+        if out is None:
+            z = lambda *shape, dt=self.dtype: torch.zeros(*shape, dtype=dt, device=dev)  # noqa: E731
+            out = {"obs": z(T + 1, E, D), "actions": z(T, E), "values": z(T, E), "logp": z(T, E), "reward": z(T, E),
+                   "done_u8": z(T, E, dt=torch.uint8), "outcome": z(T, E, dt=torch.uint8), "episode_return": z(T, E),
+                   "episode_steps": z(T, E, dt=torch.int32)}
+            out["done"] = out["done_u8"].view(torch.bool)
+        assert out["obs"].shape == (T + 1, E, D)
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        with torch.cuda.device(dev):
+            out["obs"][0].copy_(self._obs)
+            io = native.CStepIO(ptr(out["actions"]), ptr(out["obs"][1:]), ptr(out["reward"]), ptr(out["done_u8"]),
+                                ptr(out["outcome"]), None, ptr(out["episode_return"]), ptr(out["episode_steps"]))
+            ac = native.CActorCritic(native.CPolicy(*[ptr(t) for t in keep[:6]], 64, 0), *[ptr(t) for t in keep[6:]],
+                                     ptr(out["values"]), ptr(out["logp"]), int(noise_seed) & (2 ** 64 - 1),
+                                     int(noise_step) & 0xFFFFFFFF, 0)
+            fn = self._lib.acas2d_collect_f32 if self.dtype == torch.float32 else self._lib.acas2d_collect_f64
+            native.check(fn(C.byref(self._ccfg), C.byref(self._cstate), C.byref(io), C.byref(ac), ptr(out["obs"][0]), T,
+                            self.seed_value, self.env_offset, E, self.n_traffic, self._stream()))
+            self._obs.copy_(out["obs"][T])            # the observation the NEXT action would be drawn on
+        out["_weights"] = keep       # keep the transposed copies alive until the launch ran
+        return out
+
     @property
     def actions_buffer(self):
         return self._actions

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define ACAS2D_ABI_VERSION 4
+#define ACAS2D_ABI_VERSION 5
 
 /* error codes */
 #define ACAS2D_OK 0
@@ -200,6 +200,40 @@ int acas2d_rollout_policy_f64(const Acas2dConfig *cfg, const Acas2dState *state,
                               const Acas2dPolicy *policy, const void *obs_in, int32_t n_steps,
                               uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic,
                               void *stream);
+
+/*
+ * acas2d_collect_*: the collector of one PPO iteration in ONE launch -- SB3 1.1.0's `collect_rollouts` as
+ * training_main.py:44-52 runs it through `PPO.learn()`: for n_steps steps, `actions, values, log_probs =
+ * policy(obs)` (the action DRAWN from N(mean, exp(log_std))), `env.step(clip(actions, -1, 1))`.  acas2d_rollout_policy_*
+ * with the value net and the Gaussian sampling inside the kernel:
+ *   actor, obs_in, io                 as acas2d_rollout_policy_*; io->actions[t][e] receives the RAW (unclipped) action
+ *   v1t .. vb3                        the value net, same layout as the actor (mlp_extractor.value_net.{0,2}, value_net)
+ *   log_std                           float[1]
+ *   values, logp                      T[n_steps][E] outputs: V(obs_t), log N(action_t; mean_t, exp(log_std))
+ *   noise_seed, noise_step            eps ~ N(0, 1) comes from Philox4x32-10(key = noise_seed, counter = (env_offset + e,
+ *                                     noise_step + t, tag)) by Box-Muller: the stream depends on the global env index and
+ *                                     the step number only (pass the number of steps collected so far)
+ * A non-finite observation entry (the reference's NaN d_cpa in exact parallel flight, kinematics.py:48) reaches the
+ * two networks as 0; the observation itself is stored as it is.  Same work shapes as acas2d_rollout_policy_*.
+ */
+typedef struct Acas2dActorCritic {
+    Acas2dPolicy actor;
+    const void *v1t, *vb1;   /* float[D][64]  = value_net.0.weight TRANSPOSED, float[64] */
+    const void *v2t, *vb2;   /* float[64][64] = value_net.2.weight TRANSPOSED, float[64] */
+    const void *v3, *vb3;    /* float[64]     = value_net.weight,              float[1]  */
+    const void *log_std;     /* float[1] */
+    void *values, *logp;     /* T[n_steps][E] */
+    uint64_t noise_seed;
+    uint32_t noise_step;
+    uint32_t _pad;
+} Acas2dActorCritic;
+
+int acas2d_collect_f32(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
+                       const Acas2dActorCritic *ac, const void *obs_in, int32_t n_steps, uint64_t seed,
+                       int64_t env_offset, int64_t n_envs, int32_t n_traffic, void *stream);
+int acas2d_collect_f64(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
+                       const Acas2dActorCritic *ac, const void *obs_in, int32_t n_steps, uint64_t seed,
+                       int64_t env_offset, int64_t n_envs, int32_t n_traffic, void *stream);
 
 /*
  * acas2d_reset_*: replaces ACAS2DEnv.reset() (environment.py:44-48 -> ACAS2DGame.__init__,

@@ -75,7 +75,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol(g):
     for name in declared:
         assert hasattr(L, name), name
     assert set(g.native.EXPORTS) == declared
-    assert L.acas2d_abi_version() == g.native.ABI_VERSION == 4 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
+    assert L.acas2d_abi_version() == g.native.ABI_VERSION == 5 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
     assert int(re.search(r"#define ACAS2D_ABI_VERSION (\d+)", header).group(1)) == g.native.ABI_VERSION
 
 
