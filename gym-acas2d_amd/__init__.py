@@ -12,7 +12,7 @@ from . import native, records, render, reset_parity, sharding        # noqa: F40
 from .vec_env import ACAS2DVecEnv, LazyInfos                         # noqa: F401
 from .env import ACAS2DEnv, GameView, register_with_gym              # noqa: F401
 from .policy import SB3ActorPolicy, load_sb3_policy, evaluate_policy, evaluate_policy_fused  # noqa: F401
-from .ppo import ActorCritic, PPOConfig, PPOTrainer, compute_gae, ppo_loss   # noqa: F401
+from .ppo import ActorCritic, FusedUpdate, PPOConfig, PPOTrainer, compute_gae, ppo_loss   # noqa: F401
 
 register_with_gym()
 

@@ -37,10 +37,21 @@ class CActorCritic(C.Structure):
                [("noise_seed", C.c_uint64), ("noise_step", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class CPpoUpdate(C.Structure):
+    """struct Acas2dPpoUpdate: one PPO minibatch update (include/acas2d.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "actor_w1", "actor_b1", "actor_w2", "actor_b2", "actor_w3", "actor_b3", "critic_w1", "critic_b1", "critic_w2",
+        "critic_b2", "critic_w3", "critic_b3", "log_std", "obs", "act", "old_logp", "adv", "ret", "idx")] + \
+        [("n_rows", C.c_int32), ("obs_dim", C.c_int32)] + \
+        [(n, C.c_float) for n in ("clip_range", "vf_coef", "ent_coef", "max_grad_norm", "learning_rate", "beta1", "beta2",
+                                  "adam_eps")] + \
+        [(n, C.c_void_p) for n in ("grad", "adam_m", "adam_v", "adam_step", "stats")]
+
+
 EXPORTS = ("acas2d_abi_version", "acas2d_config_size", "acas2d_state_size", "acas2d_last_error", "acas2d_step_f32",
            "acas2d_step_f64", "acas2d_rollout_f32", "acas2d_rollout_f64", "acas2d_rollout_policy_f32",
-           "acas2d_rollout_policy_f64", "acas2d_collect_f32", "acas2d_collect_f64", "acas2d_reset_f32", "acas2d_reset_f64",
-           "acas2d_launch_geometry")
+           "acas2d_rollout_policy_f64", "acas2d_collect_f32", "acas2d_collect_f64", "acas2d_ppo_workspace_floats",
+           "acas2d_ppo_update_f32", "acas2d_reset_f32", "acas2d_reset_f64", "acas2d_launch_geometry")
 
 
 class NativeLibraryError(RuntimeError):
@@ -102,6 +113,10 @@ def lib():
         f.restype = C.c_int
         f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.POINTER(CStepIO), C.POINTER(CActorCritic), C.c_void_p,
                       C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+    L.acas2d_ppo_workspace_floats.restype = C.c_int
+    L.acas2d_ppo_workspace_floats.argtypes = [C.c_int32]
+    L.acas2d_ppo_update_f32.restype = C.c_int
+    L.acas2d_ppo_update_f32.argtypes = [C.POINTER(CPpoUpdate), C.c_void_p]
     for name in ("acas2d_reset_f32", "acas2d_reset_f64"):
         f = getattr(L, name)
         f.restype = C.c_int

@@ -148,13 +148,58 @@ def ppo_loss(policy, cfg, obs, act, old_logp, adv, ret):
     return pg + cfg.ent_coef * ent + cfg.vf_coef * vf, pg, vf
 
 
+class FusedUpdate:
+    """One PPO minibatch update as two hand-written launches (acas2d_ppo_update_f32, csrc/acas2d_ppo.hip): forward,
+    ppo_loss(), backward, clip_grad_norm_ and Adam for the SB3 MlpPolicy actor-critic, on the parameter tensors in
+    place.  `obs` [n, D], `act` / `old_logp` / `adv` / `ret` [n] are the flat float32 rollout buffers (their storage
+    must stay put), `idx` an int64 device tensor naming the minibatch's rows (rewritten by the caller between
+    calls).  Keeps its own Adam moments (torch.optim.Adam's arithmetic, eps 1e-5 as SB3 sets it)."""
+
+    def __init__(self, policy, cfg, obs, act, old_logp, adv, ret, beta1=0.9, beta2=0.999, adam_eps=1e-5):
+        import ctypes as C
+        from . import native
+        self._C, self._native, self._lib = C, native, native.lib()
+        dev = obs.device
+        D = obs.shape[-1]
+        n = int(self._lib.acas2d_ppo_workspace_floats(D))
+        z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt, device=dev)  # noqa: E731
+        self.grad, self.m, self.v, self.step_count, self.stats = z(n), z(n), z(n), z(1, torch.int32), z(8)
+        pn, vn = policy.mlp_extractor.policy_net, policy.mlp_extractor.value_net
+        self._params = [pn[0].weight, pn[0].bias, pn[2].weight, pn[2].bias, policy.action_net.weight, policy.action_net.bias,
+                        vn[0].weight, vn[0].bias, vn[2].weight, vn[2].bias, policy.value_net.weight, policy.value_net.bias,
+                        policy.log_std]
+        assert all(p.dtype == torch.float32 and p.is_contiguous() and p.device == dev for p in self._params)
+        self._bufs = [t.reshape(-1) if i else t.reshape(-1, D) for i, t in enumerate((obs, act, old_logp, adv, ret))]
+        assert all(t.dtype == torch.float32 and t.is_contiguous() for t in self._bufs)
+        self.cfg, self.D, self.betas, self.adam_eps, self.device = cfg, D, (beta1, beta2), adam_eps, dev
+
+    def _struct(self, idx):
+        assert idx.dtype == torch.int64 and idx.is_contiguous()
+        p = lambda t: t.data_ptr()  # noqa: E731
+        cfg = self.cfg
+        return self._native.CPpoUpdate(*[p(t) for t in self._params], *[p(t) for t in self._bufs], p(idx), idx.numel(), self.D,
+                                       cfg.clip_range, cfg.vf_coef, cfg.ent_coef, cfg.max_grad_norm, cfg.learning_rate,
+                                       self.betas[0], self.betas[1], self.adam_eps, p(self.grad), p(self.m), p(self.v),
+                                       p(self.step_count), p(self.stats))
+
+    def step(self, idx):
+        u = self._struct(idx)
+        self._native.check(self._lib.acas2d_ppo_update_f32(
+            self._C.byref(u), self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def last_losses(self):
+        s = self.stats.cpu().tolist()
+        return {"pg_loss": s[4], "value_loss": s[5], "grad_norm": s[2]}
+
+
 class PPOTrainer:
     """collector: "graphs" (default on a GPU: one captured env step replayed n_steps times), "fused" (the whole
     collection of an iteration in ONE hand-written launch, ACAS2DVecEnv.collect(): actor, critic, Gaussian sampling
     and the env step inside the kernel; its noise comes from the kernel's own Philox stream instead of torch's
-    generator) or "eager" (op by op).  The update always runs from the captured graphs when `use_graphs`."""
+    generator) or "eager" (op by op).  updater: "graphs" (default with `use_graphs`: one captured minibatch update of
+    torch ops) or "fused" (FusedUpdate: the minibatch update as two hand-written launches, its own Adam state)."""
 
-    def __init__(self, venv, config=None, policy=None, use_graphs=None, collector=None):
+    def __init__(self, venv, config=None, policy=None, use_graphs=None, collector=None, updater=None):
         self.venv = venv
         self.cfg = config or PPOConfig()
         torch.manual_seed(self.cfg.seed)
@@ -165,6 +210,10 @@ class PPOTrainer:
         if self.collector not in ("graphs", "fused", "eager") or (self.collector != "eager" and not self.use_graphs):
             raise ValueError("collector %r needs use_graphs" % (self.collector,))
         self._fused_out = None
+        self.updater = updater or "graphs"
+        if self.updater not in ("graphs", "fused") or (self.updater == "fused" and not self.use_graphs):
+            raise ValueError("updater %r needs use_graphs" % (self.updater,))
+        self._fused_update = None
         # (fused: one multi-tensor kernel for the 13 parameter tensors instead of ~10 foreach launches)
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5,
                                     capturable=self.use_graphs, **({"fused": True} if self.use_graphs else {}))
@@ -358,6 +407,21 @@ class PPOTrainer:
 
     def update(self, obs=None, act=None, old_logp=None, adv=None, ret=None, old_val=None):
         cfg = self.cfg
+        if self.use_graphs and self.updater == "fused":
+            n, B = cfg.n_steps * self.venv.num_envs, self.mb_idx.numel()
+            if self._fused_update is None:
+                self._fused_update = FusedUpdate(self.policy, cfg, self.b_obs, self.b_act, self.b_logp, self.b_adv, self.b_ret)
+            fu = self._fused_update
+            for _ in range(cfg.n_epochs):
+                perm = torch.randperm(n, device=self.device)
+                for i in range(0, n - B + 1, B):
+                    self.mb_idx.copy_(perm[i:i + B])
+                    fu.step(self.mb_idx)
+                if self.mb_tail is not None:
+                    self.mb_tail.copy_(perm[n - n % B:])
+                    fu.step(self.mb_tail)
+            st = fu.last_losses()
+            return {"pg_loss": st["pg_loss"], "value_loss": st["value_loss"], "std": self.policy.log_std.detach().exp().item()}
         if self.use_graphs:
             n, B = cfg.n_steps * self.venv.num_envs, self.mb_idx.numel()
             for _ in range(cfg.n_epochs):

@@ -236,6 +236,36 @@ int acas2d_collect_f64(const Acas2dConfig *cfg, const Acas2dState *state, const 
                        int64_t env_offset, int64_t n_envs, int32_t n_traffic, void *stream);
 
 /*
+ * acas2d_ppo_update_f32: ONE minibatch update of SB3 1.1.0's PPO.train() for the MlpPolicy actor-critic (the update
+ * half of `PPO('MlpPolicy', env).learn()`, training_main.py:44-52) as two launches: forward + PPO loss + backward of
+ * both 2 x 64 tanh networks on the rows idx[0 .. n_rows) of the rollout buffer (advantages normalised over the
+ * minibatch, clipped surrogate, MSE value loss without clipping, entropy of the state-independent Gaussian), then
+ * clip_grad_norm_ + Adam on the 13 parameter tensors IN PLACE.  Parameters in torch's own layouts ([out][in]), all
+ * float32.  grad / adam_m / adam_v: acas2d_ppo_workspace_floats(obs_dim) floats each, zero before the first call
+ * (grad is left zero by every call); adam_step: int32[1], 0 before the first call; stats: float[8], zero before
+ * the first call -- [2] gradient norm, [4] policy loss, [5] value loss of the last minibatch.
+ * obs_dim in {8, 11, 14, 17, 29} (n_traffic 1, 2, 3, 4, 8).  max_grad_norm < 0 (tests): only the gradient is
+ * computed and left in `grad` (actor w1 b1 w2 b2 w3 b3, critic likewise, log_std), nothing is applied.
+ */
+typedef struct Acas2dPpoUpdate {
+    void *actor_w1, *actor_b1, *actor_w2, *actor_b2, *actor_w3, *actor_b3;       /* mlp_extractor.policy_net.{0,2}, action_net */
+    void *critic_w1, *critic_b1, *critic_w2, *critic_b2, *critic_w3, *critic_b3; /* mlp_extractor.value_net.{0,2}, value_net  */
+    void *log_std;
+    const void *obs;                 /* float[n][obs_dim]: the rollout buffer, flat */
+    const void *act, *old_logp, *adv, *ret;   /* float[n] */
+    const int64_t *idx;              /* int64[n_rows]: the minibatch */
+    int32_t n_rows, obs_dim;
+    float clip_range, vf_coef, ent_coef, max_grad_norm;
+    float learning_rate, beta1, beta2, adam_eps;
+    void *grad, *adam_m, *adam_v;
+    int32_t *adam_step;
+    void *stats;
+} Acas2dPpoUpdate;
+
+int acas2d_ppo_workspace_floats(int32_t obs_dim);
+int acas2d_ppo_update_f32(const Acas2dPpoUpdate *u, void *stream);
+
+/*
  * acas2d_reset_*: replaces ACAS2DEnv.reset() (environment.py:44-48 -> ACAS2DGame.__init__,
  * game.py:28-41,80-116, then observe()).  For every env with mask[e] != 0 (mask == NULL: all):
  *   do_init != 0: draw a fresh episode from the Philox stream described above

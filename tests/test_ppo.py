@@ -247,6 +247,80 @@ def test_fused_collector_against_torch_and_a_twin_env(g_mod, dtype_name, N, E, T
     assert torch.equal(o4["actions"], out["actions"][:, E // 2:]) and torch.equal(o4["obs"], out["obs"][:, :, :][:, E // 2:])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,n,B", ((8, 6000, 2048 + 37), (29, 3000, 1000), (14, 700, 64)))
+def test_fused_update_against_torch_autograd_and_adam(g_mod, D, n, B):
+    """acas2d_ppo_update_f32 (two hand-written launches) against the torch path the trainer otherwise runs --
+    ppo_loss(), autograd, clip_grad_norm_, torch.optim.Adam(eps = 1e-5) -- on the same minibatch: the loss values, the
+    gradient norm and the parameters after one and after three updates (the Adam moments carry over)."""
+    g = g_mod
+    torch.manual_seed(11)
+    dev = "cuda:0"
+    cfg = g.PPOConfig(ent_coef=0.01, max_grad_norm=0.5, learning_rate=3e-4)
+    mine = _random_actor_critic(g, D, 5)
+    ref = g.ActorCritic(D).to(dev)
+    ref.load_state_dict(mine.state_dict())
+    obs = torch.rand(n, D, device=dev) * 2 - 1
+    act = torch.randn(n, device=dev) * 0.7
+    adv, ret = torch.randn(n, device=dev) * 2, torch.randn(n, device=dev)
+    with torch.no_grad():
+        mean, _ = ref.forward(obs)
+        old_logp = g.ppo._normal_logp(mean, ref.log_std, act.unsqueeze(-1)) + torch.randn(n, device=dev) * 0.25
+    # the raw gradient first (max_grad_norm < 0: nothing applied), entry for entry against autograd
+    import dataclasses
+    probe = g.FusedUpdate(mine, dataclasses.replace(cfg, max_grad_norm=-1.0), obs, act, old_logp, adv, ret)
+    idx0 = torch.randperm(n, device=dev)[:B].contiguous()
+    probe.step(idx0)
+    loss0, _, _ = g.ppo_loss(ref, cfg, obs[idx0], act[idx0].unsqueeze(-1), old_logp[idx0], adv[idx0], ret[idx0])
+    loss0.backward()
+    pn, vn = ref.mlp_extractor.policy_net, ref.mlp_extractor.value_net
+    want = torch.cat([t.grad.reshape(-1) for t in (pn[0].weight, pn[0].bias, pn[2].weight, pn[2].bias, ref.action_net.weight,
+                                                    ref.action_net.bias, vn[0].weight, vn[0].bias, vn[2].weight, vn[2].bias,
+                                                    ref.value_net.weight, ref.value_net.bias, ref.log_std)])
+    got = probe.grad.clone()
+    got[-1] -= cfg.ent_coef                                    # (the entropy term is added by the apply launch)
+    err = float((got - want).abs().max()) / float(want.abs().max())
+    cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
+    print("fused PPO gradient vs autograd (D = %d, B = %d): max |diff| / max |g| = %.2e, cosine %.8f, norms %.6g %.6g"
+          % (D, B, err, cos, float(got.norm()), float(want.norm())))
+    assert err < 2e-4 and cos > 0.999999
+    ref.zero_grad(set_to_none=True)
+    fu = g.FusedUpdate(mine, cfg, obs, act, old_logp, adv, ret)
+    opt = torch.optim.Adam(ref.parameters(), lr=cfg.learning_rate, eps=1e-5)
+    for k in range(3):
+        idx = torch.randperm(n, device=dev)[:B].contiguous()
+        loss, pg, vf = g.ppo_loss(ref, cfg, obs[idx], act[idx].unsqueeze(-1), old_logp[idx], adv[idx], ret[idx])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        norm = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), cfg.max_grad_norm))
+        opt.step()
+        fu.step(idx)
+        torch.cuda.synchronize()
+        st = fu.last_losses()
+        assert abs(st["pg_loss"] - float(pg.detach())) < 2e-5 * max(1.0, abs(float(pg.detach()))) + 2e-6, (k, st, float(pg.detach()))
+        assert abs(st["value_loss"] - float(vf.detach())) < 1e-4 * float(vf.detach()), (k, st, float(vf.detach()))
+        assert abs(st["grad_norm"] - norm) < 2e-4 * norm, (k, st["grad_norm"], norm)
+        for (name, p), q in zip(mine.named_parameters(), ref.parameters()):
+            d = float((p - q).abs().max())
+            assert d < 0.02 * cfg.learning_rate, (k, name, d)        # an Adam step moves a parameter by ~lr
+    assert int(fu.step_count) == 3 and float(fu.grad.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_ppo_learns_with_the_fused_update(g_mod):
+    """The short run of test_short_ppo_run_learns with both halves of an iteration hand-written: one launch collects,
+    two launches per minibatch update."""
+    g = g_mod
+    venv = g.ACAS2DVecEnv(1024, 1, device="cuda:0", dtype=torch.float32, seed=13)
+    tr = g.PPOTrainer(venv, g.PPOConfig(n_steps=256, batch_size=4096), collector="fused", updater="fused")
+    before = _eval_on_reference_episodes(g, tr.policy)
+    hist = tr.learn(16 * 256 * 1024, log=None)
+    assert len(hist) == 16 and np.isfinite(hist[-1]["value_loss"])
+    after = _eval_on_reference_episodes(g, tr.policy)
+    assert (after["outcome"] == 2).sum() <= 10, np.bincount(after["outcome"], minlength=4)
+    assert after["total_reward"].mean() > before["total_reward"].mean() + 50
+
+
 @pytest.fixture(scope="module")
 def g_mod():
     import gym_acas2d_amd as g

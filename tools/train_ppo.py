@@ -23,12 +23,15 @@ ap.add_argument("--n-steps", type=int, default=256)
 ap.add_argument("--batch-size", type=int, default=4096)
 ap.add_argument("--collector", choices=("graphs", "fused", "eager"), default="fused",
                 help="fused: the whole collection of an iteration in one hand-written launch (ACAS2DVecEnv.collect)")
+ap.add_argument("--updater", choices=("graphs", "fused"), default="fused",
+                help="fused: every minibatch update as two hand-written launches (acas2d_ppo_update_f32)")
+ap.add_argument("--seed", type=int, default=13)
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 
 venv = g.ACAS2DVecEnv(args.envs, args.traffic, device="cuda:0", dtype=torch.float32, seed=13)
-trainer = g.PPOTrainer(venv, g.PPOConfig(n_steps=args.n_steps, batch_size=args.batch_size), collector=args.collector,
-                       use_graphs=args.collector != "eager")
+trainer = g.PPOTrainer(venv, g.PPOConfig(n_steps=args.n_steps, batch_size=args.batch_size, seed=args.seed), collector=args.collector,
+                       use_graphs=args.collector != "eager", updater=args.updater if args.collector != "eager" else "graphs")
 hist = trainer.learn(int(args.timesteps), log=lambda r: print(json.dumps(r), flush=True))
 
 if args.traffic == 1:
