@@ -31,3 +31,19 @@ def test_no_kernel_spills_or_uses_scratch(unit, tmp_path):
         assert field(body, "sgpr_spill_count") < 400, (name, field(body, "sgpr_spill_count"))
         if "step_kernelIfLi4ELi2ELb1ELb1ELb1ELb0ELb0E" in name:                 # the headline kernel: >= 4 waves / SIMD
             assert field(body, "vgpr_count") <= 128, field(body, "vgpr_count")
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
+def test_ppo_update_kernels_stay_in_registers(tmp_path):
+    """csrc/acas2d_ppo.hip keeps three 64-entry per-lane vectors in registers (h1, dh1, a gradient row): a spill to
+    scratch there would cost far more than any wrong bit would show."""
+    asm = tmp_path / "acas2d_ppo.s"
+    subprocess.run([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only", "-o", str(asm),
+                    os.path.join(CSRC, "acas2d_ppo.hip")], check=True, capture_output=True)
+    kernels = re.findall(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", asm.read_text(), re.S)
+    assert len(kernels) == 6                                     # five observation widths + the apply kernel
+    field = lambda body, k: int(re.search(r"\.%s:\s+(\d+)" % k, body).group(1))  # noqa: E731
+    for name, body in kernels:
+        assert field(body, "vgpr_spill_count") == 0 and field(body, "sgpr_spill_count") == 0, name
+        assert field(body, "private_segment_fixed_size") == 0 and field(body, "vgpr_count") <= 256, name
