@@ -456,9 +456,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // every step).  Speed only -- any placement is correct.
 __device__ __forceinline__ int64_t remap_block(uint32_t trailing = 0u) {
     const uint32_t nb = gridDim.x - trailing, b = blockIdx.x;        // `trailing` last workgroups have another role
-#ifndef ACAS2D_EXP_NO_REMAP
     if ((nb & 7u) == 0u) return (int64_t)(b & 7u) * (nb >> 3) + (b >> 3);
-#endif
     return b;
 }
 
