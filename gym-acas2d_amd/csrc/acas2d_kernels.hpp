@@ -86,6 +86,10 @@ struct ResetParamsT {
     R own_x0, own_y0, own_v, own_heading0, own_heading_jitter, goal_x, goal_y;
     R t0_x, t0_y_base, t0_y_span, t0_heading_base, t0_heading_step, t0_heading_jitter;
     R tn_x_max, tn_y_max, speed_factor_min, speed_factor_max, airspeed;
+    // A fresh episode's player stands at (own_x0, own_y0) with the goal at (goal_x, goal_y): its goal distance,
+    // goal bearing (degrees) and deviation are constants of the config, evaluated once on the host
+    // (make_reset_params) for the FAST formulation's first observation -- see own_context_fresh().
+    R d_goal0, h_goal0, d_dev0;
 };
 // reset_kernel draws in float64 in both builds; the step kernels' in-step reset draws in the
 // element type, so the float32 build gets the constants rounded on the host (18 SGPRs instead of
@@ -581,6 +585,27 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
     return c;
 }
 
+// The player side of a freshly drawn episode's first observation (a_lat = 0, heading in [0, 360): the
+// one-step-ahead heading of closing_speed() is the heading itself, bit for bit, so its sin / cos are not
+// computed twice).  FAST: the three goal terms do not depend on the drawn heading -- the host evaluated them
+// (ResetParamsT::d_goal0 / h_goal0 / d_dev0), which takes a square root and an arctangent off the tail of
+// every wave that resets an env (65 536 x 8: float32 5.88 -> 5.74 us per launch, float64 12.1 -> 11.5).
+// EXACT keeps the reference's operations on the device.
+template <typename T, bool FAST, typename R>
+__device__ __forceinline__ OwnCtx<T> own_context_fresh(const Params<T>& p, const ResetParamsT<R>& rp, const Own<T>& o) {
+    if constexpr (FAST) {
+        OwnCtx<T> c;
+        c.x = o.x; c.y = o.y; c.v = o.v;
+        f_sincos_rev(o.psi * Const<T>::inv360, &c.so, &c.co);
+        const T vdt = o.v * p.dt;
+        c.v1x = rounded(vdt * c.co); c.v1y = rounded(vdt * c.so);
+        c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
+        c.d_goal = (T)rp.d_goal0; c.h_goal = (T)rp.h_goal0; c.d_dev = (T)rp.d_dev0;
+        return c;
+    } else {
+        return own_context<T, FAST, true>(p, o);
+    }
+}
 
 // One traffic aircraft, part 1 -- the traffic half of game.py:222-247 action(): wrap the heading,
 // sin / cos of it, Euler step when `move`.  In/out: tx, ty (moved), tpsi (wrapped); out: st, ct.
@@ -1020,7 +1045,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetPa
     if constexpr (kOneTermPass) { if (io.term_obs && lane < D) (io.term_obs + e * D)[lane] = term_v; }
     psi_own = lane_value(psi_own, 0);
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-    const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
+    const OwnCtx<T> c = own_context_fresh<T, FAST>(p, rp, o);
 
     ACAS2D_STAMP(10, wave_dbg, lane, false);
     // environment.py:44-48: the new episode's first observation (steps becomes 1)
@@ -1143,7 +1168,7 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
         psi_own = have ? scr[4 * N] : T(0);
     }
     const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-    const OwnCtx<T> c = own_context<T, FAST, true>(p, o);
+    const OwnCtx<T> c = own_context_fresh<T, FAST>(p, rp, o);
     // environment.py:44-48: the new episodes' first observations (steps becomes 1)
     if (mine) {
         if (ent >= 1) {
@@ -1681,7 +1706,14 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
             steps += 1;
             T d_sep = T(0);
             auto sep = [&](const OwnCtx<T>&) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); };
-            const Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row, true, nullptr, sep);
+            Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row, true, nullptr, sep);
+            if constexpr (FAST) {
+                if (do_init) {                            // the same goal terms as the in-step reset: own_context_fresh()
+                    OwnCtx<T> c0;
+                    c0.d_goal = r.d_goal = (T)rp.d_goal0; c0.h_goal = r.h_goal = (T)rp.h_goal0; c0.d_dev = r.d_dev = (T)rp.d_dev0;
+                    if (j == 0) put_own_obs<T, FAST>(p, row, steps, o.psi, c0);
+                }
+            }
             if (s.trace && j == 0)                        // game.py:132-160: the records' first entries
                 write_trace<T, FAST>(p, s.trace + el * kTraceWidth, o.psi, d_sep, T(0), r.h_goal, r.d_goal, r.d_dev, r.v_closing0,
                                      r.d_cpa0, step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev));

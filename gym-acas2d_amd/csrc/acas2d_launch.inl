@@ -4,6 +4,7 @@
 // type is compiled with its own flags.  Both use -ffp-contract=off today, so only the fma()s written
 // in the source fuse.)
 #include <stdlib.h>
+#include <cmath>
 
 #include "acas2d_kernels.hpp"
 
@@ -29,10 +30,16 @@ static Params<T> make_params(const Acas2dConfig& c) {
 
 template <typename R>
 static ResetParamsT<R> make_reset_params(const Acas2dConfig& c) {
+    // the goal terms of a fresh episode (own_context_fresh()): game.py:168-180 at the start position
+    const double gdx = c.goal_x - c.own_x0, gdy = c.goal_y - c.own_y0;
+    double bearing = std::atan2(gdy, gdx);
+    if (bearing < 0) bearing += 6.283185307179586476925;
+    else if (bearing == 0) bearing = 0;
     return ResetParamsT<R>{(R)c.own_x0, (R)c.own_y0, (R)c.own_v, (R)c.own_heading0, (R)c.own_heading_jitter,
                            (R)c.goal_x, (R)c.goal_y, (R)c.t0_x, (R)c.t0_y_base, (R)c.t0_y_span,
                            (R)c.t0_heading_base, (R)c.t0_heading_step, (R)c.t0_heading_jitter, (R)c.tn_x_max,
-                           (R)c.tn_y_max, (R)c.speed_factor_min, (R)c.speed_factor_max, (R)c.airspeed};
+                           (R)c.tn_y_max, (R)c.speed_factor_min, (R)c.speed_factor_max, (R)c.airspeed,
+                           (R)std::sqrt(std::fma(gdy, gdy, gdx * gdx)), (R)(bearing * 57.29577951308232087680), (R)gdy};
 }
 
 template <typename T>
