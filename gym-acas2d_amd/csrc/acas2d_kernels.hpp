@@ -81,7 +81,7 @@ __device__ __forceinline__ Params<T> pinned(Params<T> p) {
 
 // reset distribution (game.py:80-116); evaluated in float64 for both instantiations so that a
 // seed names the same episode in f32 and f64, then rounded to T once.
-template <typename R>
+template <typename R, typename GT = R>
 struct ResetParamsT {
     R own_x0, own_y0, own_v, own_heading0, own_heading_jitter, goal_x, goal_y;
     R t0_x, t0_y_base, t0_y_span, t0_heading_base, t0_heading_step, t0_heading_jitter;
@@ -89,16 +89,15 @@ struct ResetParamsT {
     // A fresh episode's player stands at (own_x0, own_y0) with the goal at (goal_x, goal_y): its goal distance,
     // goal bearing (degrees) and deviation are constants of the config, evaluated once on the host
     // (make_reset_params) for the FAST formulation's first observation -- see own_context_fresh().
-    R d_goal0, h_goal0, d_dev0;
+    GT d_goal0, h_goal0, d_dev0;                          // in the element type also where the draws are float64
 };
 // reset_kernel draws in float64 in both builds; the step kernels' in-step reset draws in the
 // element type, so the float32 build gets the constants rounded on the host (18 SGPRs instead of
 // 36 and no v_cvt_f32_f64 on the reset path).
-using ResetParams = ResetParamsT<double>;
 // (the fused rollout keeps float64 constants: with the float set the compiler settles on a register
 // allocation for that kernel that runs 7 % slower -- measured, 3.07e10 vs 3.3e10 env-steps/s)
 template <typename T, bool ROLLOUT>
-using StepResetParams = ResetParamsT<typename std::conditional<ROLLOUT, double, T>::type>;
+using StepResetParams = ResetParamsT<typename std::conditional<ROLLOUT, double, T>::type, T>;
 
 // Per-step record row behind testing_main.py:114-138's CSV columns (the lists ACAS2DGame appends to at
 // game.py:132-160, :231-241, :266-276): psi, d_sep, a_lat, d_goal, delta_heading, v_closing, d_cpa, d_dev,
@@ -592,7 +591,7 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
 // every wave that resets an env (65 536 x 8: float32 5.88 -> 5.74 us per launch, float64 12.1 -> 11.5).
 // EXACT keeps the reference's operations on the device.
 template <typename T, bool FAST, typename R>
-__device__ __forceinline__ OwnCtx<T> own_context_fresh(const Params<T>& p, const ResetParamsT<R>& rp, const Own<T>& o) {
+__device__ __forceinline__ OwnCtx<T> own_context_fresh(const Params<T>& p, const R& rp, const Own<T>& o) {
     if constexpr (FAST) {
         OwnCtx<T> c;
         c.x = o.x; c.y = o.y; c.v = o.v;
@@ -912,7 +911,7 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
 // 32 random bits per uniform; the float32 build draws in float32 from 24 bits (equal to the float64
 // evaluation rounded to float32 up to 1-2 ulp, at a fraction of its latency).
 template <typename T, typename R>
-__device__ __forceinline__ void reset_entity(const ResetParamsT<R>& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
+__device__ __forceinline__ void reset_entity(const R& rp, uint32_t k0, uint32_t k1, uint32_t g_lo,
                                              uint32_t g_hi, uint32_t episode, int ent, T& ox, T& oy, T& opsi,
                                              T& ov) {
 #pragma clang fp contract(off)
@@ -946,7 +945,7 @@ __device__ __forceinline__ void reset_entity(const ResetParamsT<R>& rp, uint32_t
 // reset() for one env by its owner group: lane j draws its own traffic aircraft (and, redundantly, the
 // player's heading), stores the new state and returns the player.
 template <typename T, int C, int G, bool PACKED, typename R>
-__device__ __forceinline__ Own<T> reset_env(const ResetParamsT<R>& rp, const State<T>& s, uint32_t k0,
+__device__ __forceinline__ Own<T> reset_env(const R& rp, const State<T>& s, uint32_t k0,
                                             uint32_t k1, uint64_t gid, uint32_t episode, int e,
                                             int j, int N, Traffic<T, C>& tr) {
     const uint32_t g_lo = (uint32_t)gid, g_hi = (uint32_t)(gid >> 32);
@@ -990,7 +989,7 @@ __device__ __forceinline__ Own<T> reset_env(const ResetParamsT<R>& rp, const Sta
 // and it leaves with the wave's ordinary, coalesced state stores and its single tile flush.  Without
 // it (generic walk) the entity lanes store the new state themselves and the caller re-flushes the row.
 template <typename T, bool FAST, int NS, bool HANDOFF, typename R>
-__device__ __forceinline__ void wave_reset_env(const Params<T>& p, const ResetParamsT<R>& rp, const State<T>& s,
+__device__ __forceinline__ void wave_reset_env(const Params<T>& p, const R& rp, const State<T>& s,
                                                const StepIO<T>& io, uint32_t k0, uint32_t k1, uint64_t gid,
                                                int e, int N_dyn, int lane, T total, int32_t steps,
                                                uint32_t episode_prev, T* __restrict__ row,
@@ -1104,7 +1103,7 @@ template <typename T, int NS> struct SlotLayout {
 // group leader, i.e. el * G); returns the mask of those bits.  Owner lanes find their slot as the rank of
 // their bit in the returned mask.  Whole wave, wave-uniform arguments.
 template <typename T, bool FAST, int NS, int G, typename R>
-__device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& p, const ResetParamsT<R>& rp,
+__device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& p, const R& rp,
                                                                const StepIO<T>& io, uint32_t k0, uint32_t k1,
                                                                uint64_t gid_wave, unsigned long long dm, int lane,
                                                                uint32_t episode_lane, T* __restrict__ tile,
@@ -1673,7 +1672,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
 
 // ACAS2DEnv.reset(), environment.py:44-48 (do_init != 0: fresh episodes; == 0: keep the injected state).
 template <typename T, int C, int G, bool PACKED, bool FAST>
-__global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetParams rp, State<T> s_arg,
+__global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, StepResetParams<T, true> rp, State<T> s_arg,
                                                        const uint8_t* __restrict__ mask, T* obs,
                                                        int do_init, uint32_t k0, uint32_t k1,
                                                        int64_t env_offset, int64_t n_envs, int N,
@@ -1706,17 +1705,17 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, ResetPar
             steps += 1;
             T d_sep = T(0);
             auto sep = [&](const OwnCtx<T>&) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); };
-            Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row, true, nullptr, sep);
-            if constexpr (FAST) {
-                if (do_init) {                            // the same goal terms as the in-step reset: own_context_fresh()
-                    OwnCtx<T> c0;
-                    c0.d_goal = r.d_goal = (T)rp.d_goal0; c0.h_goal = r.h_goal = (T)rp.h_goal0; c0.d_dev = r.d_dev = (T)rp.d_dev0;
-                    if (j == 0) put_own_obs<T, FAST>(p, row, steps, o.psi, c0);
-                }
+            const Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, false, tr, row, true, nullptr, sep);
+            // FAST, fresh episodes: the same goal terms as the in-step reset -- own_context_fresh()
+            const bool fresh = FAST && do_init;
+            const T d_goal = fresh ? (T)rp.d_goal0 : r.d_goal, h_goal = fresh ? (T)rp.h_goal0 : r.h_goal,
+                    d_dev = fresh ? (T)rp.d_dev0 : r.d_dev;
+            if (fresh && j == 0) {                        // put_own_obs(), entries 2..4
+                row[2] = d_dev * p.inv_d_dev_max; row[3] = d_goal * p.inv_d_goal_max; row[4] = h_goal * Const<T>::inv360;
             }
             if (s.trace && j == 0)                        // game.py:132-160: the records' first entries
-                write_trace<T, FAST>(p, s.trace + el * kTraceWidth, o.psi, d_sep, T(0), r.h_goal, r.d_goal, r.d_dev, r.v_closing0,
-                                     r.d_cpa0, step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev));
+                write_trace<T, FAST>(p, s.trace + el * kTraceWidth, o.psi, d_sep, T(0), h_goal, d_goal, d_dev, r.v_closing0,
+                                     r.d_cpa0, step_reward_5<T, FAST>(p, r.v_closing0, o.psi, h_goal, r.d_cpa0, d_goal, d_dev));
             wave_lds_fence();
             T* dst = obs + (e_wave + el) * D;             // masked rows are not contiguous: per-row copy
             for (int i = j; i < D; i += G) dst[i] = row[i];

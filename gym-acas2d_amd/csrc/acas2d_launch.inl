@@ -28,18 +28,18 @@ static Params<T> make_params(const Acas2dConfig& c) {
     return p;
 }
 
-template <typename R>
-static ResetParamsT<R> make_reset_params(const Acas2dConfig& c) {
+template <typename R, typename GT = R>
+static ResetParamsT<R, GT> make_reset_params(const Acas2dConfig& c) {
     // the goal terms of a fresh episode (own_context_fresh()): game.py:168-180 at the start position
     const double gdx = c.goal_x - c.own_x0, gdy = c.goal_y - c.own_y0;
     double bearing = std::atan2(gdy, gdx);
     if (bearing < 0) bearing += 6.283185307179586476925;
     else if (bearing == 0) bearing = 0;
-    return ResetParamsT<R>{(R)c.own_x0, (R)c.own_y0, (R)c.own_v, (R)c.own_heading0, (R)c.own_heading_jitter,
+    return ResetParamsT<R, GT>{(R)c.own_x0, (R)c.own_y0, (R)c.own_v, (R)c.own_heading0, (R)c.own_heading_jitter,
                            (R)c.goal_x, (R)c.goal_y, (R)c.t0_x, (R)c.t0_y_base, (R)c.t0_y_span,
                            (R)c.t0_heading_base, (R)c.t0_heading_step, (R)c.t0_heading_jitter, (R)c.tn_x_max,
                            (R)c.tn_y_max, (R)c.speed_factor_min, (R)c.speed_factor_max, (R)c.airspeed,
-                           (R)std::sqrt(std::fma(gdy, gdy, gdx * gdx)), (R)(bearing * 57.29577951308232087680), (R)gdy};
+                           (GT)std::sqrt(std::fma(gdy, gdy, gdx * gdx)), (GT)(bearing * 57.29577951308232087680), (GT)gdy};
 }
 
 template <typename T>
@@ -103,7 +103,7 @@ static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, c
 }
 
 template <typename T, bool FAST, int C, int G>
-static void rollout_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
+static void rollout_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const StepResetParams<T, true>& rp,
                           const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
                           int64_t n_envs, int N, int n_steps) {
     hipLaunchKernelGGL((step_kernel<T, C, G, true, true, FAST, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
@@ -112,7 +112,7 @@ static void rollout_shape(const Geometry& g, hipStream_t stream, const Params<T>
 
 // the same with the SB3 actor evaluated in the kernel (thread-per-env shapes only)
 template <typename T, bool FAST, int C>
-static void policy_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
+static void policy_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const StepResetParams<T, true>& rp,
                          const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
                          int64_t n_envs, int N, int n_steps, const PolicyW& pw, bool sample) {
     if (sample)
@@ -124,7 +124,7 @@ static void policy_shape(const Geometry& g, hipStream_t stream, const Params<T>&
 }
 
 template <typename T, bool FAST, int C, int G, bool PACKED>
-static void reset_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const ResetParams& rp,
+static void reset_shape(const Geometry& g, hipStream_t stream, const Params<T>& p, const StepResetParams<T, true>& rp,
                         const State<T>& s, const uint8_t* mask, T* obs, int do_init, uint32_t k0, uint32_t k1,
                         int64_t env_offset, int64_t n_envs, int N) {
     hipLaunchKernelGGL((reset_kernel<T, C, G, PACKED, FAST>), dim3(g.grid), dim3(kBlock),
@@ -215,7 +215,7 @@ static int launch_rollout_impl(const Acas2dConfig* cfg, const Acas2dState* st, c
     Geometry g;
     if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
-    const ResetParams rp = make_reset_params<double>(*cfg);
+    const StepResetParams<T, true> rp = make_reset_params<double, T>(*cfg);
     const State<T> s = make_state<T>(*st);
     const StepIO<T> io{(const T*)io_->actions, (T*)io_->obs, (T*)io_->reward, io_->done, io_->outcome,
                        (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
@@ -253,7 +253,7 @@ static int launch_rollout_policy_impl(const Acas2dConfig* cfg, const Acas2dState
     Geometry g;
     if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
-    const ResetParams rp = make_reset_params<double>(*cfg);
+    const StepResetParams<T, true> rp = make_reset_params<double, T>(*cfg);
     const State<T> s = make_state<T>(*st);
     const StepIO<T> io{(const T*)io_->actions, (T*)io_->obs, (T*)io_->reward, io_->done, io_->outcome,
                        (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
@@ -289,7 +289,7 @@ static int launch_reset_impl(const Acas2dConfig* cfg, const Acas2dState* st, con
     Geometry g;
     if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
-    const ResetParams rp = make_reset_params<double>(*cfg);
+    const StepResetParams<T, true> rp = make_reset_params<double, T>(*cfg);
     const State<T> s = make_state<T>(*st);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     if (do_init < 0) { set_error("acas2d_reset: do_init = %d", do_init); return ACAS2D_EINVAL; }
