@@ -14,6 +14,7 @@ import csv
 import glob
 import json
 import os
+import re
 import statistics
 import sys
 
@@ -23,9 +24,12 @@ N, S = 8, 4
 
 def counter(name, E):
     vals = []
-    for f in glob.glob(os.path.join(d, "pmc_%s_%d" % (name, E), "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(d, "pmc_%s_%d" % (name, E), "**", "*counter_collection.csv"), recursive=True)
+    files += glob.glob(os.path.join(d, "keep", "pmc_%s_%d_step_kernel.csv" % (name, E)))   # the extract profile_round.sh keeps
+    for f in files[:1]:
         for r in csv.DictReader(open(f)):
-            if "step_kernel<float, 4, 2, true, true, true, false, false>" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            # the per-step kernel only: ROLLOUT / POLICY / SAMPLE all false
+            if re.search(r"step_kernel<float, 4, 2, true, true, true(, false)+>", r["Kernel_Name"]) and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"]))
     vals = vals[len(vals) // 4:]
     return statistics.mean(vals) if vals else None
