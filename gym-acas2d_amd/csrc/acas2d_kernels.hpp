@@ -1423,6 +1423,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                      "s"(rp.goal_x), "s"(rp.goal_y), "s"(rp.t0_x), "s"(rp.t0_y_base), "s"(rp.t0_y_span),
                      "s"(rp.t0_heading_base), "s"(rp.t0_heading_step), "s"(rp.t0_heading_jitter), "s"(rp.tn_x_max),
                      "s"(rp.tn_y_max), "s"(rp.speed_factor_min), "s"(rp.speed_factor_max), "s"(rp.airspeed),
+                     "s"(rp.d_goal0), "s"(rp.h_goal0), "s"(rp.d_dev0),
                      "s"(k0), "s"(k1), "s"(io_arg.ep_steps));
     }
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
