@@ -18,6 +18,8 @@ ap.add_argument("--envs", type=int, default=65536)
 ap.add_argument("--traffic", type=int, default=8)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--no-terminations", action="store_true")
+ap.add_argument("--no-collisions", action="store_true", help="fewer finished envs per step (goal arrivals and time-outs only)")
+ap.add_argument("--warm-steps", type=int, default=300)
 args = ap.parse_args()
 
 g.native.LIB_PATH = os.path.join(ROOT, "gym-acas2d_amd", "csrc", os.environ.get("ACAS2D_DIAG_LIB", "libacas2d_hip_diag.so"))
@@ -26,6 +28,8 @@ L = g.native.lib()
 env = g.ACAS2DVecEnv(args.envs, args.traffic, device="cuda:0", dtype=torch.float32, seed=13)
 if args.no_terminations:
     env._ccfg.collision_dist = 0.0; env._ccfg.goal_radius = 0.0; env._ccfg.max_steps = 2 ** 30
+if args.no_collisions:
+    env._ccfg.collision_dist = 0.0
 geo = g.native.launch_geometry(args.envs, args.traffic, 4)
 n_waves = geo["grid_blocks"] * 4
 buf = torch.zeros(n_waves, 16, dtype=torch.int64, device="cuda:0")
@@ -34,7 +38,7 @@ assert L.acas2d_debug_set_stamps_f32(buf.data_ptr()) == 0
 env.reset()
 gen = torch.Generator(device="cuda:0").manual_seed(0)
 acts = torch.rand(64, args.envs, generator=gen, device="cuda:0") * 2 - 1
-for t in range(300):
+for t in range(args.warm_steps):
     env.step_from(acts[t % 64])
 S, E_, D = [], [], []
 for t in range(args.steps):
@@ -60,6 +64,13 @@ last = E_.argmax(1)
 print("last wave to end: its start percentile %s, had a finished env %s" %
       (np.round([(S[i] < S[i, last[i]]).mean() for i in range(len(S))], 2)[:12], D[np.arange(len(S)), last][:12]))
 fin = D
+print("waves with a finished env per launch: %.1f; their end percentiles [50, 90, 100]: %s; lifetime percentiles: %s" %
+      (fin.sum(1).mean(), np.round(np.percentile(E_[fin], [50, 90, 100]), 2) if fin.any() else None,
+       np.round(np.percentile((E_ - S)[fin], [50, 90, 100]), 2) if fin.any() else None))
+# waves that share a SIMD: a block's wave w runs on SIMD w of its CU, the CU holds two blocks -- which two is the
+# dispatcher's choice, so pairs are not identified here; the count of blocks with >= 2 resetting waves is
+blk_fin = fin.reshape(fin.shape[0], -1, 4)
+print("blocks with a resetting wave per launch: %.1f, with two or more: %.1f" % (blk_fin.any(2).sum(1).mean(), (blk_fin.sum(2) >= 2).sum(1).mean()))
 print("waves with a finished env: length median %.2f us, others %.2f us; end median %.2f vs %.2f" %
       (np.median((E_ - S)[fin]), np.median((E_ - S)[~fin]), np.median(E_[fin]), np.median(E_[~fin])))
 late = S > np.percentile(S, 90, axis=1, keepdims=True)
