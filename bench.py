@@ -72,6 +72,7 @@ def parse(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip the other single-GPU BASELINE configs")
     ap.add_argument("--rollout-steps", type=int, default=200)
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic: latch outcomes instead of resetting")
+    ap.add_argument("--in-place", action="store_true", help="A/B: step the state in place instead of double-buffered")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-collisions", action="store_true",
                     help="diagnostic (SURVEY.md 8d, C4): collision distance 0, so episodes end at the goal / by "
@@ -168,14 +169,17 @@ def cpu_baseline(envs, traffic, seconds):
     return out
 
 
-def load_traffic(envs, traffic, dtype):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if one exists
-    for exactly this workload; else null."""
+def load_traffic(envs, traffic, dtype, detail=False):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json, written by
+    tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE passes of THIS command), if one exists for exactly
+    this workload; else null.  `detail`: the whole record -- the read side under both corrections (the guide's x 2 for
+    wide coalesced reads, and the factor fitted at 4 M envs where every input byte is fetched exactly once), the
+    build the passes were taken on."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         for rec in json.load(open(p)):
             if (rec["envs"], rec["traffic"], rec["dtype"]) == (envs, traffic, dtype):
-                return rec["hbm_bytes_per_launch"]
+                return rec if detail else rec["hbm_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         pass
     return None
@@ -198,8 +202,11 @@ class StepRunner:
         self.env, self.rows, self.chunk = env, [actions[t] for t in range(actions.shape[0])], actions.shape[0]
         self.graph = None
         if use_graph:
+            if self.chunk % 2 and getattr(env, "double_buffer", False):
+                env.set_double_buffer(False)      # a replayed graph must hold an even number of double-buffered steps
             self.eager(3)
             torch.cuda.synchronize()
+            self.gen0 = getattr(env, "generation", 0)     # the state generation the captured launches start from
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.eager(self.chunk)
@@ -213,6 +220,8 @@ class StepRunner:
             self.eager(n)
             return
         full, rest = divmod(n, self.chunk)
+        if full and hasattr(self.env, "align_generation"):
+            self.env.align_generation(self.gen0)          # no-op unless an odd number of eager steps ran in between
         for _ in range(full):
             self.graph.replay()
         self.eager(rest)
@@ -235,7 +244,8 @@ class StepRunner:
 
 def make_env(g, E, N, dtype, dev, rank, args, fast_math=False):
     env = g.ACAS2DVecEnv(E, N, device=dev, dtype=dtype, seed=13, env_offset=rank * E,
-                         auto_reset=not args.no_auto_reset, config=g.ACAS2DConfig(n_traffic=N, fast_math=fast_math))
+                         auto_reset=not args.no_auto_reset, config=g.ACAS2DConfig(n_traffic=N, fast_math=fast_math),
+                         double_buffer=False if (args.in_place or args.no_auto_reset) else None)
     if args.no_collisions or args.no_terminations:
         env._ccfg.collision_dist = 0.0
     if args.no_terminations:
@@ -245,16 +255,20 @@ def make_env(g, E, N, dtype, dev, rank, args, fast_math=False):
     return env
 
 
-def time_config(g, E, N, dtype_name, dev, args, steps=1000, chunk=100):
-    """One secondary single-GPU configuration: per-launch time by HIP events over `steps` graph-replayed
-    steps after a short spin.  Returns the numbers of the roofline line for that workload."""
+def time_config(g, E, N, dtype_name, dev, args, steps=1000, chunk=100, rank=0, sync_ranks=None):
+    """One secondary configuration: per-launch time by HIP events over `steps` graph-replayed steps after a short
+    spin.  Returns the numbers of the roofline line for that workload.  `sync_ranks` (multi-GPU): a barrier in front
+    of the timed steps; the caller takes the MAX of launch_us over the ranks."""
     import torch
     dtype = torch.float32 if dtype_name == "f32" else torch.float64
-    env = make_env(g, E, N, dtype, dev, 0, args, fast_math=dtype_name == "f64-fast")
+    env = make_env(g, E, N, dtype, dev, rank, args, fast_math=dtype_name == "f64-fast")
     gen = torch.Generator(device=dev).manual_seed(1000)
     actions = torch.rand(chunk, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
     runner = StepRunner(env, actions, True)
     runner.spin(0.1)
+    if sync_ranks is not None:
+        torch.cuda.synchronize()
+        sync_ranks()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     runner.run(steps)
@@ -268,6 +282,10 @@ def time_config(g, E, N, dtype_name, dev, args, steps=1000, chunk=100):
            "env_steps_per_s": E / (us * 1e-6), "algorithmic_bytes_per_launch": b,
            "achieved_GBps": b / (us * 1e-6) / 1e9, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
            "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"], "steps": steps}
+    tr = load_traffic(E, N, dtype_name, detail=True)
+    if tr is not None:
+        out["traffic"] = tr["hbm_bytes_per_launch"]
+        out["traffic_over_algorithmic"] = tr["hbm_bytes_per_launch"] / b
     del runner, env, actions
     return out
 
@@ -297,6 +315,7 @@ def main():
         g.native.LIB_PATH = os.path.join(ROOT, "gym-acas2d_amd", "csrc", os.environ["ACAS2D_BENCH_LIB"])
     rank, local_rank, world = g.sharding.dist_env()
     args.gpus = world
+    fail_rank = os.environ.get("ACAS2D_BENCH_FAIL_RANK")        # tests only: this rank dies after the rendezvous
     E, N, K, W = args.envs, args.traffic, args.steps, args.warmup
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
 
@@ -305,6 +324,8 @@ def main():
         g.sharding.init_process_group("gloo")
         env = RehearsalEnv(E)
         sync = lambda: None  # noqa: E731
+        if fail_rank is not None and int(fail_rank) == rank:
+            sys.exit(3)
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
         dev_index = local_rank if args.device is None else args.device
@@ -383,6 +404,20 @@ def main():
         except Exception as e:  # noqa: BLE001
             fused = {"error": str(e)}
 
+    # ---- multi-GPU: BASELINE.json configs[3] as well -- 1 048 576 envs over 8 GPUs = 131 072 per GPU;
+    #      every rank times its shard behind a barrier, the line carries the MAX launch time and the whole-job rate
+    c3 = None
+    if world > 1 and not args.rehearsal and not args.no_extra and (E, N, args.dtype) == (65536, 8, "f32"):
+        try:
+            mine = time_config(g, 131072, 8, "f32", dev, args, steps=1000, chunk=100, rank=rank, sync_ranks=barrier)
+            us = g.sharding.max_over_ranks(mine["launch_us"], device=red_dev)
+            b = mine["algorithmic_bytes_per_launch"]
+            c3 = {"workload": "%d envs x N_TRAFFIC=8 over %d GPUs (131072 per GPU), f32" % (131072 * world, world),
+                  "launch_us_max_over_ranks": us, "value": 131072 * world / (us * 1e-6), "unit": "env-steps/s",
+                  "per_gpu_achieved_GBps": b / (us * 1e-6) / 1e9, "per_gpu_frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                  "steps": mine["steps"]}
+        except Exception as e:  # noqa: BLE001
+            c3 = {"error": str(e)}
     if rank == 0:
         s = 4 if args.dtype == "f32" else 8
         bytes_per_launch = E * g.ACAS2DConfig.algorithmic_bytes_per_env_step(N, s)
@@ -394,7 +429,7 @@ def main():
             "metric": METRIC,
             "value": E * world * timed_steps / wall,
             "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "repeats": repeats,
+            "n_gpus": world, "steps": K, "warmup": W, "repeats": repeats, "timed_steps": timed_steps,
             "ms_per_step": wall * 1e3 / timed_steps,
             "higher_is_better": True,
             "scaling": "weak",
@@ -417,13 +452,17 @@ def main():
                                          % (E, N, args.dtype, " (FAST formulation)" if args.fast_math and args.dtype == "f64" else "",
                                             "off" if args.no_auto_reset else "on", diag),
                              "envs_per_gpu": E, "n_traffic": N, "launch": args.launch, "steps_per_graph": chunk,
+                             "state_buffers": "double (read generation g, write 1 - g)" if getattr(env, "double_buffer", False)
+                                              else "in place",
                              "warmup_graph_replays": spin_replays,
                              "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"],
                              "grid_blocks": geo["grid_blocks"],
                              "parallelism": "env-index shards x%d, no collective on the step path" % world,
                              "episodes_finished": int(episodes)}
+            tr = load_traffic(E, N, args.dtype, detail=True)
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(E, N, args.dtype),
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                               "traffic_detail": tr,
                                "kernel": "acas2d::step_kernel<%s, C=%d, G=%d>" % ("float" if s == 4 else "double",
                                                                                   geo["traffic_per_lane"], geo["lanes_per_env"]),
                                "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -433,15 +472,18 @@ def main():
         if world == 1 and not args.rehearsal and not args.no_extra:
             # the other single-GPU configurations of BASELINE.json (parity-test cases; reported, not `value`)
             extra = []
-            for (e2, n2, d2) in ((4096, 3, "f32"), (65536, 64, "f32"), (65536, 8, "f64"), (65536, 8, "f64-fast"),
-                                 (131072, 8, "f32")):
+            # (the last one: 1.5 GB of working set >> the 256 MB Infinity Cache -- the true-HBM data point)
+            for (e2, n2, d2, st2) in ((4096, 3, "f32", 1000), (65536, 64, "f32", 1000), (65536, 8, "f64", 1000),
+                                      (65536, 8, "f64-fast", 1000), (131072, 8, "f32", 1000), (4194304, 8, "f32", 100)):
                 if (e2, n2, d2) == (E, N, args.dtype):
                     continue
                 try:
-                    extra.append(time_config(g, e2, n2, d2, dev, args))
+                    extra.append(time_config(g, e2, n2, d2, dev, args, steps=st2, chunk=min(100, st2)))
                 except Exception as e:  # noqa: BLE001
                     extra.append({"workload": "%d x %d %s" % (e2, n2, d2), "error": str(e)})
             out["other_configs"] = extra
+        if c3 is not None:
+            out["configs3_shard"] = c3
         if world == 1 and not args.no_cpu_baseline and not args.rehearsal:
             out["cpu_baseline"] = cpu_baseline(E, N, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -52,11 +52,22 @@ int main(int argc, char** argv) {
     // one zeroed allocation per array (the library allocates nothing and keeps no state)
     auto dmalloc = [](size_t bytes, void** p) { hipError_t e = hipMalloc(p, bytes); return e == hipSuccess ? hipMemset(*p, 0, bytes) : e; };
     Acas2dState st = {};
-    void** f_e[] = {&st.own_x, &st.own_y, &st.own_psi, &st.own_v, &st.goal_x, &st.goal_y, &st.total_reward};
+    void** f_e[] = {&st.own_v, &st.goal_x, &st.goal_y};
     for (void** p : f_e) HIP(dmalloc(E * sizeof(float), p));
-    void** f_en[] = {&st.trf_x, &st.trf_y, &st.trf_psi, &st.trf_v};
+    void** f_en[] = {&st.trf_psi, &st.trf_v};
     for (void** p : f_en) HIP(dmalloc(E * N * sizeof(float), p));
-    HIP(dmalloc(E * 4, (void**)&st.steps)); HIP(dmalloc(E, (void**)&st.status)); HIP(dmalloc(E * 4, (void**)&st.episode));
+    HIP(dmalloc(E, (void**)&st.status)); HIP(dmalloc(E * 4, (void**)&st.episode));
+    // the arrays a step rewrites for every env are double-buffered: [2][E] / [2][E][N] each, `st` on the first halves,
+    // `st2` on the second (acas2d.h, acas2d_step_*'s state_out); every other buffer is shared
+    void** g_e[] = {&st.own_x, &st.own_y, &st.own_psi, &st.total_reward, (void**)&st.steps};      // 4-byte elements all
+    for (void** p : g_e) HIP(dmalloc(2 * E * sizeof(float), p));
+    void** g_en[] = {&st.trf_x, &st.trf_y};
+    for (void** p : g_en) HIP(dmalloc(2 * E * N * sizeof(float), p));
+    Acas2dState st2 = st;
+    st2.own_x = (float*)st.own_x + E; st2.own_y = (float*)st.own_y + E; st2.own_psi = (float*)st.own_psi + E;
+    st2.total_reward = (float*)st.total_reward + E; st2.steps = st.steps + E;
+    st2.trf_x = (float*)st.trf_x + E * N; st2.trf_y = (float*)st.trf_y + E * N;
+    const Acas2dState* gen[2] = {&st, &st2};
     Acas2dStepIO io = {};
     void *actions, *obs, *reward;
     HIP(dmalloc(E * sizeof(float), &actions)); HIP(dmalloc(E * D * sizeof(float), &obs)); HIP(dmalloc(E * sizeof(float), &reward));
@@ -72,7 +83,7 @@ int main(int argc, char** argv) {
     long long finished = 0;
     double reward_sum = 0;
     for (int t = 0; t < steps; ++t) {
-        ACAS(acas2d_step_f32(&cfg, &st, &io, ACAS2D_AUTO_RESET, seed, 0, E, N, stream));
+        ACAS(acas2d_step_f32(&cfg, gen[t & 1], gen[(t + 1) & 1], &io, ACAS2D_AUTO_RESET, seed, 0, E, N, stream));   // read one generation, write the other
         HIP(hipMemcpyAsync(done.data(), io.done, E, hipMemcpyDeviceToHost, stream));
         HIP(hipMemcpyAsync(rew.data(), reward, E * sizeof(float), hipMemcpyDeviceToHost, stream));
         HIP(hipStreamSynchronize(stream));

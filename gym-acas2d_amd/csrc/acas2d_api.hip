@@ -50,13 +50,13 @@ size_t acas2d_config_size(void) { return sizeof(Acas2dConfig); }
 size_t acas2d_state_size(void) { return sizeof(Acas2dState); }
 const char* acas2d_last_error(void) { return g_error; }
 
-int acas2d_step_f32(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dStepIO* io, uint32_t flags,
-                    uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, void* stream) {
-    return launch_step<float>(cfg, state, io, flags, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
+int acas2d_step_f32(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dState* state_out, const Acas2dStepIO* io,
+                    uint32_t flags, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, void* stream) {
+    return launch_step<float>(cfg, state, state_out, io, flags, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
 }
-int acas2d_step_f64(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dStepIO* io, uint32_t flags,
-                    uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, void* stream) {
-    return launch_step<double>(cfg, state, io, flags, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
+int acas2d_step_f64(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dState* state_out, const Acas2dStepIO* io,
+                    uint32_t flags, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, void* stream) {
+    return launch_step<double>(cfg, state, state_out, io, flags, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
 }
 int acas2d_rollout_f32(const Acas2dConfig* cfg, const Acas2dState* state, const Acas2dStepIO* io, int32_t n_steps,
                        uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, void* stream) {

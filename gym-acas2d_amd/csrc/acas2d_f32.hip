@@ -7,7 +7,7 @@ constexpr bool kFast = true;
 }
 #include "acas2d_launch.inl"
 namespace acas2d {
-template int launch_step<float>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, uint32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
+template int launch_step<float>(const Acas2dConfig*, const Acas2dState*, const Acas2dState*, const Acas2dStepIO*, uint32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int launch_rollout<float>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int launch_rollout_policy<float>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, const Acas2dPolicy*, const void*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int launch_collect<float>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, const Acas2dActorCritic*, const void*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);

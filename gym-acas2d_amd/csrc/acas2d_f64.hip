@@ -7,7 +7,7 @@ constexpr bool kFast = false;
 }
 #include "acas2d_launch.inl"
 namespace acas2d {
-template int launch_step<double>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, uint32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
+template int launch_step<double>(const Acas2dConfig*, const Acas2dState*, const Acas2dState*, const Acas2dStepIO*, uint32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int launch_rollout<double>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int launch_rollout_policy<double>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, const Acas2dPolicy*, const void*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int launch_collect<double>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, const Acas2dActorCritic*, const void*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);

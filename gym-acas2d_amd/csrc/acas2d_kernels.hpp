@@ -79,8 +79,9 @@ __device__ __forceinline__ Params<T> pinned(Params<T> p) {
     return p;
 }
 
-// reset distribution (game.py:80-116); evaluated in float64 for both instantiations so that a
-// seed names the same episode in f32 and f64, then rounded to T once.
+// reset distribution (game.py:80-116).  R = the type the constants arrive in; reset_entity() evaluates the draws
+// in the ELEMENT type: (seed, global env index, episode counter) names one episode per element type, and the
+// float32 episode equals the float64 one up to float32 rounding (24 random bits per uniform instead of 32).
 template <typename R, typename GT = R>
 struct ResetParamsT {
     R own_x0, own_y0, own_v, own_heading0, own_heading_jitter, goal_x, goal_y;
@@ -91,11 +92,11 @@ struct ResetParamsT {
     // (make_reset_params) for the FAST formulation's first observation -- see own_context_fresh().
     GT d_goal0, h_goal0, d_dev0;                          // in the element type also where the draws are float64
 };
-// reset_kernel draws in float64 in both builds; the step kernels' in-step reset draws in the
-// element type, so the float32 build gets the constants rounded on the host (18 SGPRs instead of
-// 36 and no v_cvt_f32_f64 on the reset path).
-// (the fused rollout keeps float64 constants: with the float set the compiler settles on a register
-// allocation for that kernel that runs 7 % slower -- measured, 3.07e10 vs 3.3e10 env-steps/s)
+// reset_kernel, the in-step reset and the fused rollout all draw through reset_entity<T>() (bit-identical per
+// element type: test_f32_reset_names_the_same_episodes).  The per-step float32 kernel gets the constants rounded
+// on the host (18 SGPRs instead of 36 and no v_cvt_f32_f64 on the reset path); reset_kernel and the fused
+// rollout take them as float64 and convert at the use (with the float set the compiler settles on a register
+// allocation for the rollout kernel that runs 7 % slower -- measured, 3.07e10 vs 3.3e10 env-steps/s).
 template <typename T, bool ROLLOUT>
 using StepResetParams = ResetParamsT<typename std::conditional<ROLLOUT, double, T>::type, T>;
 
@@ -113,6 +114,11 @@ struct State {
     uint8_t* status;
     uint32_t* episode;
     T* trace;                 // optional [E][kTraceWidth] (latching kernels and reset only), see write_trace()
+    // Double-buffered state (acas2d_step_* with a `state_out`): the arrays a step REWRITES for every env -- own_x,
+    // own_y, own_psi, steps, total_reward, trf_x, trf_y -- are read here and written `w_env` (per-env arrays) /
+    // `w_trf` (traffic arrays) ELEMENTS further on, i.e. into the other generation's buffers (0 = in place).  See
+    // put_env() / put_trf() and "store policies" below for why.
+    int32_t w_env, w_trf;
 };
 
 template <typename T>
@@ -132,7 +138,7 @@ __device__ __forceinline__ State<T> rebase(const State<T>& s, int64_t e0, int N)
     return State<T>{s.own_x + e0, s.own_y + e0, s.own_psi + e0, s.own_v + e0, s.goal_x + e0, s.goal_y + e0,
                     s.trf_x + e0 * N, s.trf_y + e0 * N, s.trf_psi + e0 * N, s.trf_v + e0 * N,
                     s.steps + e0, s.total_reward + e0, s.status + e0, s.episode + e0,
-                    s.trace ? s.trace + e0 * kTraceWidth : nullptr};
+                    s.trace ? s.trace + e0 * kTraceWidth : nullptr, s.w_env, s.w_trf};
 }
 template <typename T>
 __device__ __forceinline__ StepIO<T> rebase(const StepIO<T>& io, int64_t e0, int D) {
@@ -493,12 +499,16 @@ __device__ __forceinline__ float uniformf(float a, float b, float u) { return fm
 // (L2s are not coherent across XCDs, so a kernel boundary flushes them) -- AFTER the last wave has finished, with
 // nothing left to overlap it.  Measured at 65 536 x 8, reset-free (tools/run_variants.sh, one box):
 //   observations (7.6 MB, never re-read on the device)   plain 7.1 us per launch   non-temporal 4.8
-//   + state (traffic x / y, per-env scalars: 5.9 MB)      non-temporal 4.7 - 4.9 (no gain)
+//   + state (traffic x / y, per-env scalars: 5.9 MB), IN PLACE   non-temporal 4.7 - 4.9 (no gain: a store that hits a
+//       line the launch LOADED earlier leaves it dirty whatever its hint)
+//   + state into ANOTHER buffer (double-buffered state: read generation g, write generation 1 - g; State::w_env /
+//       w_trf, acas2d_step_*'s state_out)   non-temporal 4.23 against 4.65 in place, same box -- the 5.9 MB leave
+//       the L2s during the launch like the observations do, instead of in the write-back after its last wave
 //   everything write-through (sc1)                        4.3 -- but UNSAFE and therefore not used: the kernel's
 //       completion does not wait for write-through stores still in flight (with or without s_waitcnt vmcnt(0)
 //       before s_endpgm, agent or system scope), and a device-to-host copy right behind the launch read stale
 //       observation rows in one run out of four (the full-size float64 parity test of tests/test_gpu_parity.py).
-// So: observations non-temporal, state plain.
+// So: observations non-temporal; state non-temporal and, where the caller passes a second generation, out of place.
 
 // ---- per-lane vector of C traffic values ---------------------------------------------------------
 template <typename T, int C>
@@ -508,6 +518,35 @@ struct alignas((C * sizeof(T)) % 16 == 0 ? 16 : ((C * sizeof(T)) % 8 == 0 ? 8 : 
 
 template <typename T, int W>
 __device__ __forceinline__ void store_chunk(Vec<T, W>* dst, const Vec<T, W>& v);
+
+// Stores into the arrays a step rewrites for every env, to the WRITE generation (State::w_env / w_trf), non-temporal.
+// `e` / `i0`: the element index the same value was read at.
+template <typename T, typename U>
+__device__ __forceinline__ void put_env(const State<T>& s, U* base, int e, U v) {
+#ifdef ACAS2D_STATE_PLAIN
+    base[e + s.w_env] = v;
+#else
+    __builtin_nontemporal_store(v, base + (e + s.w_env));
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void put_trf1(const State<T>& s, T* base, int i, T v) {
+#ifdef ACAS2D_STATE_PLAIN
+    base[i + s.w_trf] = v;
+#else
+    __builtin_nontemporal_store(v, base + (i + s.w_trf));
+#endif
+}
+template <typename T, int C>
+__device__ __forceinline__ void put_trf(const State<T>& s, T* base, int i0, const Vec<T, C>& v) {
+    Vec<T, C>* dst = reinterpret_cast<Vec<T, C>*>(base + (i0 + s.w_trf));
+#ifdef ACAS2D_STATE_PLAIN
+    *dst = v;
+#else
+    if constexpr ((C & (C - 1)) == 0) store_chunk<T, C>(dst, v);
+    else *dst = v;                                          // 3 aircraft per lane: one 12- / 24-byte store
+#endif
+}
 
 // ---- one env's player, as every lane of its group sees it ------------------------------------------
 // A product rounded to T that the compiler can never contract into an fma, whatever the build's
@@ -531,11 +570,22 @@ struct Own {
 // Player-side terms shared by every traffic aircraft of the env.
 template <typename T>
 struct OwnCtx {
-    T x, y, v;
+    T x, y;
     T co, so;             // cos / sin of the player's heading                (kinematics.py:35-36)
     T v1x, v1y, x1, y1;   // closing_speed(): one-step-ahead projection        (kinematics.py:56-65)
     T d_goal, h_goal, d_dev;
+    T v;                  // (last: next to x and y, hipcc slices the three into one vector and extracts (y, v) through scratch)
 };
+
+// The player-side terms are broadcast operands of the packed float2 arithmetic.  Left to itself hipcc gathers
+// neighbouring fields of the struct into a vector and extracts the pairs it wants from it THROUGH SCRATCH MEMORY
+// (scratch_store_dwordx4 + three overlapping scratch_load_dwordx2 in the middle of the step); an empty asm per
+// field keeps every one of them an independent scalar.
+template <typename T>
+__device__ __forceinline__ void scalars(OwnCtx<T>& c) {
+    asm("" : "+v"(c.x)); asm("" : "+v"(c.y)); asm("" : "+v"(c.v)); asm("" : "+v"(c.co)); asm("" : "+v"(c.so));
+    asm("" : "+v"(c.v1x)); asm("" : "+v"(c.v1y)); asm("" : "+v"(c.x1)); asm("" : "+v"(c.y1));
+}
 
 // What the reward / termination need back from observe().
 template <typename T>
@@ -567,6 +617,7 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
         if constexpr (sizeof(T) == 4) c.h_goal = rounded(atan2_rev(gdy, gdx) * T(360));
         else c.h_goal = relative_angle(o.x, o.y, o.gx, o.gy);
         c.d_dev = gdy;            // d_goal * sin(atan2(gdy, gdx)) == gdy          (game.py:175-180)
+        scalars(c);
     } else {
         m_sincos(deg2rad_ref(o.psi), &c.so, &c.co);
         T s1 = c.so, c1 = c.co;
@@ -600,6 +651,7 @@ __device__ __forceinline__ OwnCtx<T> own_context_fresh(const Params<T>& p, const
         c.v1x = rounded(vdt * c.co); c.v1y = rounded(vdt * c.so);
         c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
         c.d_goal = (T)rp.d_goal0; c.h_goal = (T)rp.h_goal0; c.d_dev = (T)rp.d_dev0;
+        scalars(c);
         return c;
     } else {
         return own_context<T, FAST, true>(p, o);
@@ -626,16 +678,28 @@ __device__ __forceinline__ void traffic_move(const Params<T>& p, bool move, T& t
     }
 }
 
-// Part 2 -- the raw (un-normalised) values behind the three observation entries of
-// game.py:205-210 for an aircraft at (tx, ty) with heading sin / cos (st, ct).
+// Part 2a -- the distance to the player (game.py:205 / :185-189): the collision test needs nothing else, so it is
+// computed for all of a lane's aircraft BEFORE the rest of their observation entries (see observe(): the outcome of
+// the step is known at that point).
+template <typename T, bool FAST>
+__device__ __forceinline__ T traffic_dist(const OwnCtx<T>& c, T tx, T ty) {
+    if constexpr (FAST) {
+        const T dx = tx - c.x, dy = ty - c.y;
+        return f_sqrt(m_fma(dy, dy, dx * dx));
+    } else {
+        return distance(c.x, c.y, tx, ty);
+    }
+}
+
+// Part 2b -- the other two raw (un-normalised) values behind the observation entries of game.py:205-210 for an
+// aircraft at (tx, ty), `d` = traffic_dist() away, with heading sin / cos (st, ct).
 template <typename T, bool FAST>
 __device__ __forceinline__ void traffic_observe(const Params<T>& p, const OwnCtx<T>& c, T tx, T ty, T tv,
-                                                T st, T ct, T& d, T& dca, T& vc) {
+                                                T st, T ct, T d, T& dca, T& vc) {
     if constexpr (FAST) {
         const T tvdt = tv * p.dt;
         const T v2x = rounded(tvdt * ct), v2yt = tvdt * st;
         const T dx = tx - c.x, dy = ty - c.y;
-        d = f_sqrt(m_fma(dy, dy, dx * dx));
         // kinematics.py:40-49: d sin(a_rel - arctan(v12y / v12x))
         //   == sign(v12x) (dy v12x - dx v12y) / |v12|   (sign bit of v12x, so -0.0 counts as
         //   negative like the quotient's; v12 == 0 gives 0 * inf = NaN like the reference's 0/0)
@@ -648,7 +712,6 @@ __device__ __forceinline__ void traffic_observe(const Params<T>& p, const OwnCtx
         const T ax = c.v1x - v2x, ay = c.v1y - v2y, bx = c.x1 - x2, by = c.y1 - y2;
         vc = (m_fma(ay, by, ax * bx) * f_rsq(m_fma(by, by, bx * bx))) * p.inv_dt;
     } else {
-        d = distance(c.x, c.y, tx, ty);
         // kinematics.py:40-49 distance_closest_approach (arctan of a quotient, signed result)
         const T a_rel_rad = deg2rad_ref(relative_angle(c.x, c.y, tx, ty));
         const T v12x = c.v * c.co - tv * ct, v12y = c.v * c.so - tv * st;
@@ -667,6 +730,7 @@ __device__ __forceinline__ void traffic_step(const Params<T>& p, const OwnCtx<T>
                                              T& ty, T& tpsi, T tv, T& d, T& dca, T& vc) {
     T st, ct;
     traffic_move<T, FAST>(p, move, tx, ty, tpsi, tv, st, ct);
+    d = traffic_dist<T, FAST>(c, tx, ty);
     traffic_observe<T, FAST>(p, c, tx, ty, tv, st, ct, d, dca, vc);
 }
 
@@ -703,12 +767,15 @@ struct TrigCache {
     bool dirty = false;      // a wrap changed a heading that has not been stored yet
 };
 
+__device__ __forceinline__ F2 traffic_dist2(const OwnCtx<float>& c, F2 tx, F2 ty) {
+    const F2 dx = tx - c.x, dy = ty - c.y;
+    return f_sqrt(m_fma(dy, dy, dx * dx));
+}
 __device__ __forceinline__ void traffic_observe2(const Params<float>& p, const OwnCtx<float>& c, F2 tx, F2 ty, F2 tv,
-                                                 F2 st, F2 ct, F2& d, F2& dca, F2& vc) {
+                                                 F2 st, F2 ct, F2& dca, F2& vc) {
     const F2 tvdt = tv * p.dt;
     const F2 v2x = rounded(tvdt * ct), v2yt = tvdt * st;
     const F2 dx = tx - c.x, dy = ty - c.y;
-    d = f_sqrt(m_fma(dy, dy, dx * dx));
     const F2 v12x = rounded(c.v * c.co) - rounded(tv * ct), v12y = rounded(c.v * c.so) - rounded(tv * st);
     const F2 cross = m_fma(dy, v12x, -(dx * v12y));
     const F2 sgn = F2{m_copysign(1.0f, v12x.x), m_copysign(1.0f, v12x.y)};
@@ -788,12 +855,19 @@ __device__ __forceinline__ T minimum_separation(const State<T>& s, const Own<T>&
 // of a wave's loads are in flight together) and write the moved block back; the generic walk
 // loads / stores aircraft by aircraft.
 // `after_own(c)` runs between the player side and the traffic side (the record rows' minimum separation).
-struct NoHook { template <typename X> __device__ __forceinline__ void operator()(const X&) const {} };
-template <typename T, int C, int G, bool PACKED, bool FAST, typename Hook = NoHook>
+// `outcome_known(d_goal, collided)` (packed shapes) runs as soon as the step's outcome is decided -- the player has moved
+// (d_goal), every aircraft of the env has moved and its distance to the player is known (collided = OR over the
+// env's group), i.e. before the closest-approach / closing-speed arithmetic of the observation.
+struct NoHook {
+    template <typename X> __device__ __forceinline__ void operator()(const X&) const {}
+    template <typename X> __device__ __forceinline__ void operator()(X, int) const {}
+};
+template <typename T, int C, int G, bool PACKED, bool FAST, typename Hook = NoHook, typename Early = NoHook>
 __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
                                            int e, int j, int N, int32_t steps, bool move,
                                            Traffic<T, C>& tr, T* __restrict__ row, bool store_traffic = true,
-                                           TrigCache<T, C>* tc = nullptr, Hook after_own = Hook()) {
+                                           TrigCache<T, C>* tc = nullptr, Hook after_own = Hook(),
+                                           Early outcome_known = Early()) {
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
     // Keep the traffic arithmetic below this line: the player side above needs only the scalars, which
     // were requested first, so it runs under s_waitcnt vmcnt(11..5) while the traffic vectors land.
@@ -849,20 +923,37 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
         // rollout: a wrapped heading waits in registers for the last step's store
         if (tc != nullptr) { tc->dirty |= psi_changed; psi_changed = tc->dirty; }
         if (move && store_traffic) {
-            *reinterpret_cast<V*>(s.trf_x + i0) = tr.x;
-            *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+            put_trf<T, C>(s, s.trf_x, i0, tr.x);
+            put_trf<T, C>(s, s.trf_y, i0, tr.y);
             if (psi_changed) {                                                  // injected headings >= 360 only
                 *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi;
                 if (tc != nullptr) tc->dirty = false;
             }
         }
+        T dist[C];
         if constexpr (PAIRS) {
 #pragma unroll
             for (int k = 0; k < C; k += 2) {
-                F2 d, dca, vc;
-                traffic_observe2(p, c, F2{tr.x.v[k], tr.x.v[k + 1]}, F2{tr.y.v[k], tr.y.v[k + 1]},
-                                 F2{tr.v.v[k], tr.v.v[k + 1]}, F2{st[k], st[k + 1]}, F2{ct[k], ct[k + 1]}, d, dca, vc);
+                const F2 d = traffic_dist2(c, F2{tr.x.v[k], tr.x.v[k + 1]}, F2{tr.y.v[k], tr.y.v[k + 1]});
                 coll |= ((d.x < p.collision_dist) | (d.y < p.collision_dist)) ? 1 : 0;   // game.py:185-189
+                dist[k] = d.x; dist[k + 1] = d.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                dist[k] = traffic_dist<T, FAST>(c, tr.x.v[k], tr.y.v[k]);
+                coll |= (dist[k] < p.collision_dist) ? 1 : 0;                    // game.py:185-189
+            }
+        }
+        r.collided = group_or<G>(coll);
+        outcome_known(c.d_goal, r.collided);
+        if constexpr (PAIRS) {
+#pragma unroll
+            for (int k = 0; k < C; k += 2) {
+                F2 dca, vc;
+                const F2 d{dist[k], dist[k + 1]};
+                traffic_observe2(p, c, F2{tr.x.v[k], tr.x.v[k + 1]}, F2{tr.y.v[k], tr.y.v[k + 1]},
+                                 F2{tr.v.v[k], tr.v.v[k + 1]}, F2{st[k], st[k + 1]}, F2{ct[k], ct[k + 1]}, dca, vc);
                 const F2 dn = d * p.inv_d_sep_max, cn = dca * p.inv_d_cpa_max, vn = vc * p.inv_v_closing_max;
                 T* q = row + 5 + 3 * (j * C + k);                                 // game.py:205-210
                 q[0] = dn.x; q[1] = cn.x; q[2] = vn.x; q[3] = dn.y; q[4] = cn.y; q[5] = vn.y;
@@ -871,10 +962,9 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
         } else {
 #pragma unroll
             for (int k = 0; k < C; ++k) {
-                T d, dca, vc;
-                traffic_observe<T, FAST>(p, c, tr.x.v[k], tr.y.v[k], tr.v.v[k], st[k], ct[k], d, dca, vc);
-                coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
-                put_traffic_obs<T, FAST>(p, row + 5 + 3 * (j * C + k), d, dca, vc);
+                T dca, vc;
+                traffic_observe<T, FAST>(p, c, tr.x.v[k], tr.y.v[k], tr.v.v[k], st[k], ct[k], dist[k], dca, vc);
+                put_traffic_obs<T, FAST>(p, row + 5 + 3 * (j * C + k), dist[k], dca, vc);
                 if (k == 0) { vc0 = vc; dc0 = dca; }
             }
         }
@@ -886,16 +976,16 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
             T d, dca, vc;
             traffic_step<T, FAST>(p, c, move, tx, ty, tpsi, tv, d, dca, vc);
             if (move) {
-                s.trf_x[i] = tx;
-                s.trf_y[i] = ty;
+                put_trf1(s, s.trf_x, i, tx);
+                put_trf1(s, s.trf_y, i, ty);
                 if (tpsi != psi_in) s.trf_psi[i] = tpsi;
             }
             coll |= (d < p.collision_dist) ? 1 : 0;                          // game.py:185-189
             put_traffic_obs<T, FAST>(p, row + 5 + 3 * n, d, dca, vc);
             if (n == 0) { vc0 = vc; dc0 = dca; }
         }
+        r.collided = group_or<G>(coll);
     }
-    r.collided = group_or<G>(coll);
     r.v_closing0 = group_bcast0<G>(vc0);                  // evaluate() reads traffic[0] only,
     r.d_cpa0 = group_bcast0<G>(dc0);                      // game.py:254-255
     if (j == 0) put_own_obs<T, FAST>(p, row, steps, o.psi, c);
@@ -1025,7 +1115,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const R& rp, 
             scratch[n] = tx; scratch[N + n] = ty; scratch[2 * N + n] = tpsi; scratch[3 * N + n] = tv;
         } else {
             const int i = e * N + (lane - 1);
-            s.trf_x[i] = tx; s.trf_y[i] = ty; s.trf_psi[i] = tpsi; s.trf_v[i] = tv;
+            s.trf_x[i + s.w_trf] = tx; s.trf_y[i + s.w_trf] = ty; s.trf_psi[i] = tpsi; s.trf_v[i] = tv;
         }
     }
     if constexpr (NS == 0 || NS > 63) {
@@ -1036,7 +1126,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const R& rp, 
                 scratch[n] = x; scratch[N + n] = y; scratch[2 * N + n] = ps; scratch[3 * N + n] = v;
             } else {
                 const int i = e * N + n;
-                s.trf_x[i] = x; s.trf_y[i] = y; s.trf_psi[i] = ps; s.trf_v[i] = v;
+                s.trf_x[i + s.w_trf] = x; s.trf_y[i + s.w_trf] = y; s.trf_psi[i] = ps; s.trf_v[i] = v;
             }
         }
     }
@@ -1057,7 +1147,7 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const R& rp, 
         for (int n = lane + 63; n < N; n += 64) {
             T x, y, ps, v;                                         // written by this lane above
             if constexpr (HANDOFF) { x = scratch[n]; y = scratch[N + n]; ps = scratch[2 * N + n]; v = scratch[3 * N + n]; }
-            else { const int i = e * N + n; x = s.trf_x[i]; y = s.trf_y[i]; ps = s.trf_psi[i]; v = s.trf_v[i]; }
+            else { const int i = e * N + n; x = s.trf_x[i + s.w_trf]; y = s.trf_y[i + s.w_trf]; ps = s.trf_psi[i]; v = s.trf_v[i]; }
             T d, dca, vc;
             traffic_step<T, FAST>(p, c, false, x, y, ps, v, d, dca, vc);
             put_traffic_obs<T, FAST>(p, row + 5 + 3 * n, d, dca, vc);
@@ -1068,10 +1158,10 @@ __device__ __forceinline__ void wave_reset_env(const Params<T>& p, const R& rp, 
             if (io.ep_return) io.ep_return[e] = total;
             if (io.ep_steps) io.ep_steps[e] = steps;
             s.episode[e] = episode;
-            s.own_x[e] = o.x; s.own_y[e] = o.y; s.own_psi[e] = o.psi; s.own_v[e] = o.v;
+            put_env(s, s.own_x, e, o.x); put_env(s, s.own_y, e, o.y); put_env(s, s.own_psi, e, o.psi); s.own_v[e] = o.v;
             s.goal_x[e] = o.gx; s.goal_y[e] = o.gy;
-            s.steps[e] = 1;                                               // environment.py:47
-            s.total_reward[e] = T(0);
+            put_env(s, s.steps, e, (int32_t)1);                           // environment.py:47
+            put_env(s, s.total_reward, e, T(0));
         }
         put_own_obs<T, FAST>(p, row, 1, o.psi, c);
     }
@@ -1179,6 +1269,123 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
         }
     }
     return taken;
+}
+
+// ---- the reset worker: a fifth wavefront per workgroup that draws the fresh episodes ---------------------------------
+// Per-step launches of the packed shapes with N + 1 <= 32 (acas2d_step_* with ACAS2D_AUTO_RESET).  A wave's
+// instruction stream issues at most one VALU instruction every four cycles however idle its SIMD is, and the reset
+// of a finished env is ~300 dependent instructions (Philox block, the drawn entity, the first observation) that the
+// finishing wave used to run AFTER its ordinary work, alone, while the launch waited for it (a wave with a finished
+// env lived 0.76 us longer than the others).  The outcome of a step is known long before its
+// observation is complete -- after the player and the traffic have moved and the distances are known (observe()'s
+// `outcome_known` hook) -- so the four stepping waves post their finishing envs to a mailbox in LDS at that point and
+// go on with the closest-approach / closing-speed / reward arithmetic, while the WORKER wave draws the new episodes
+// and their first observations into LDS slots, several envs side by side (ResetSlots: one entity per lane, the same
+// per-lane functions as the in-wave reset, hence the same bits).  At its end a stepping wave with finished envs
+// copies the fresh rows into its tile, hands the finished rows to term_obs and picks the new state up (commit).
+//
+// Protocol (words in LDS; a wave's DS operations execute in issue order):
+//   stepping wave:  takes request numbers r, r+1, ... for its finishing envs (one ds_add_rtn on n_req), writes
+//                   list[r] = (wave, env, episode counter), then adds 1 to `posted` -- every live stepping wave
+//                   does that last step, whatever it found;
+//   worker:         waits for posted == live stepping waves, reads n_req and serves the requests in batches of SLOTS
+//                   (request r -> slot r % SLOTS): before batch b > 0 it waits for consumed >= b * SLOTS (the slots
+//                   are free again), after each batch it sets served = b + 1; then it leaves;
+//   stepping wave:  at its end, for each of its finishing envs in turn: waits for served > r / SLOTS, commits slot
+//                   r % SLOTS, adds 1 to `consumed`.
+// No wait is circular: the worker waits for posts that are unconditional and for commits of batches it has already
+// served; a stepping wave waits for batches in increasing order.  Every wave of the grid reaches its end.
+struct WorkerBox {
+    uint32_t posted, n_req, served, consumed;
+    uint32_t pad[12];
+    uint32_t list[256][2];                                 // per request: wave << 16 | env in the wave, episode counter
+};
+constexpr int kWorkerBoxHead = 16;                         // words the worker clears
+template <typename T, int NS> struct WorkerSlot {          // one slot, in values of T: the state block, then the fresh row
+    static constexpr int W = 16 / (int)sizeof(T);
+    static constexpr int ROW = SlotLayout<T, NS>::STRIDE;
+    static constexpr int STRIDE = ROW + (5 + 3 * NS + W - 1) / W * W;
+};
+template <int C, int G, bool PACKED, bool AUTO_RESET, bool ROLLOUT> struct UsesWorker {
+#ifdef ACAS2D_NO_WORKER
+    static constexpr bool value = false;
+#else
+    static constexpr bool value = PACKED && AUTO_RESET && !ROLLOUT && ResetSlots<PACKED ? C * G : 1>::SLOTS >= 2 && kWavesPerBlock == 4;
+#endif
+};
+// mailbox words: volatile accesses in the LDS address space (ds_read_b32 / ds_write_b32 / ds_add, never flat)
+typedef __attribute__((address_space(3))) volatile uint32_t LdsWord;
+typedef __attribute__((address_space(3))) uint32_t LdsAtomicWord;
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return *(const LdsWord*)p; }
+__device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { *(LdsWord*)p = v; }
+__device__ __forceinline__ uint32_t lds_peek_s(const uint32_t* p) {            // wave-uniform address: the value as a scalar
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_peek(p));
+}
+__device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) {
+    return __hip_atomic_fetch_add((LdsAtomicWord*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The worker wave.  `gid_block`: global index of the workgroup's first env, `n_main`: its live stepping waves.
+template <typename T, bool FAST, int NS, int G, typename R>
+__device__ __forceinline__ void reset_worker(const Params<T>& p, const R& rp, uint32_t k0, uint32_t k1, uint64_t gid_block,
+                                             int n_main, int lane, WorkerBox* box, T* __restrict__ slots) {
+    using RS = ResetSlots<NS>;
+    using WS = WorkerSlot<T, NS>;
+    constexpr int N = NS, EPW = 64 / G;
+    const int slot = lane / RS::STRIDE, ent = lane % RS::STRIDE;
+    // (what the generation reads from the kernel arguments, fetched before the wait instead of behind it)
+    asm volatile("" :: "s"(k0), "s"(k1), "s"(gid_block), "s"(rp.own_x0), "s"(rp.own_heading0), "s"(rp.t0_x), "s"(rp.tn_x_max),
+                 "s"(rp.airspeed), "s"(rp.d_goal0), "s"(rp.d_dev0));
+    while (lds_peek_s(&box->posted) != (uint32_t)n_main) __builtin_amdgcn_s_sleep(2);
+    const int n_req = (int)lds_peek_s(&box->n_req);        // final: every stepping wave has taken its numbers
+    for (int b = 0; b * RS::SLOTS < n_req; ++b) {
+        if (b > 0)                                          // the slots are free once the previous batch has been committed
+            while (lds_peek_s(&box->consumed) < (uint32_t)(b * RS::SLOTS)) __builtin_amdgcn_s_sleep(2);
+        // ---- the fresh episodes of the batch, one entity per lane: wave_reset_slots() without the term_obs part ----
+#ifndef ACAS2D_WORKER_PRIO
+#define ACAS2D_WORKER_PRIO 2
+#endif
+        __builtin_amdgcn_s_setprio(ACAS2D_WORKER_PRIO);    // the youngest wave of its SIMD would otherwise get the leftover issue slots
+        const int r = b * RS::SLOTS + slot;
+        const bool have = r < n_req;
+        const uint32_t who = have ? lds_peek(&box->list[r][0]) : 0u;
+        const uint32_t episode = have ? lds_peek(&box->list[r][1]) + 1u : 0u;
+        const uint64_t gid = gid_block + (uint64_t)((who >> 16) * EPW + (who & 0xffffu));
+        T* scr = slots + slot * WS::STRIDE;
+        T* frow = scr + WS::ROW;
+        T tx = T(0), ty = T(0), tpsi = T(0), tv = T(0);
+        const bool mine = have && ent <= N;
+        if (mine) {
+            reset_entity<T, R>(rp, k0, k1, (uint32_t)gid, (uint32_t)(gid >> 32), episode, ent, tx, ty, tpsi, tv);
+            if (ent == 0) scr[4 * N] = tpsi;
+            else { const int n = ent - 1; scr[n] = tx; scr[N + n] = ty; scr[2 * N + n] = tpsi; scr[3 * N + n] = tv; }
+        }
+        T psi_own;
+        if constexpr (sizeof(T) == 4 && RS::STRIDE == 16)
+            psi_own = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int((float)tpsi), 0x150, 0xf, 0xf, false));
+        else if constexpr (sizeof(T) == 4 && RS::STRIDE == 4)
+            psi_own = __int_as_float(quad_perm<0x00>(__float_as_int((float)tpsi)));
+        else if constexpr (sizeof(T) == 4 && RS::STRIDE == 2)
+            psi_own = __int_as_float(quad_perm<0xA0>(__float_as_int((float)tpsi)));
+        else {
+            wave_lds_fence();                              // the player's heading of every slot is in its state block
+            psi_own = have ? scr[4 * N] : T(0);
+        }
+        const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+        const OwnCtx<T> c = own_context_fresh<T, FAST>(p, rp, o);
+        if (mine) {                                        // environment.py:44-48: the first observation (steps becomes 1)
+            if (ent >= 1) {
+                T d, dca, vc;
+                traffic_step<T, FAST>(p, c, false, tx, ty, tpsi, tv, d, dca, vc);
+                put_traffic_obs<T, FAST>(p, frow + 5 + 3 * (ent - 1), d, dca, vc);
+            } else {
+                put_own_obs<T, FAST>(p, frow, 1, o.psi, c);
+            }
+        }
+        wave_lds_fence();
+        __builtin_amdgcn_s_setprio(0);
+        if (lane == 0) lds_poke(&box->served, (uint32_t)(b + 1));     // (DS operations execute in order: the slots are written)
+    }
 }
 
 // Flush the wave's LDS tile (`count` values, the contiguous slice dst[0 .. count) of obs[E][D])
@@ -1343,7 +1550,7 @@ __device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&
 // a non-finite observation entry reaches the networks as 0 (the reference's NaN d_cpa in exact parallel flight).
 template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false,
           bool SAMPLE = false>
-__global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
+__global__ __launch_bounds__((UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::value ? kBlock + 64 : kBlock)) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
                                                       int tile_elems, int n_steps, PolicyW pw) {
@@ -1361,20 +1568,43 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         asm volatile("" :: "s"(nb), "s"(n_envs), "s"(s_arg.own_x), "s"(s_arg.own_y), "s"(s_arg.own_psi), "s"(s_arg.own_v),
                      "s"(s_arg.goal_x), "s"(s_arg.goal_y), "s"(s_arg.trf_x), "s"(s_arg.trf_y), "s"(s_arg.trf_psi),
                      "s"(s_arg.trf_v), "s"(s_arg.steps), "s"(s_arg.total_reward), "s"(s_arg.episode), "s"(io_arg.actions),
-                     "s"(tile_elems));
+                     "s"(tile_elems), "s"(s_arg.w_env), "s"(s_arg.w_trf));
     }
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
     const int wib = wave_in_block();
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    // Worker shapes (see reset_worker()): the workgroup has a fifth wave; the mailbox and the slots follow the four tiles.
+    constexpr bool WORKER = UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::value;
+    WorkerBox* const box = reinterpret_cast<WorkerBox*>(lds_raw + (size_t)kWavesPerBlock * tile_elems * sizeof(T));
+    T* const wslots = reinterpret_cast<T*>(lds_raw + (size_t)kWavesPerBlock * tile_elems * sizeof(T) + sizeof(WorkerBox));
+    if constexpr (WORKER) {
+        if (wib == kWavesPerBlock) {
+            if (lane < kWorkerBoxHead) lds_poke(reinterpret_cast<uint32_t*>(box) + lane, 0u);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the mailbox is clear ...
+            __builtin_amdgcn_s_barrier();                      // ... before any stepping wave posts to it
+#ifdef ACAS2D_WORKER_NOP
+            return;                                            // diagnostic (runs where nothing finishes only): the fifth wave's cost alone
+#endif
+            const int64_t e_block = remap_block() * kWavesPerBlock * EPW;
+            const int64_t left = n_envs - e_block;             // > 0: the workgroup exists for its first env
+            const int n_main = (int)(left >= (int64_t)kWavesPerBlock * EPW ? kWavesPerBlock : (left + EPW - 1) / EPW);
+            reset_worker<T, FAST, NS, G>(p_arg, rp, k0, k1, (uint64_t)(env_offset + e_block), n_main, lane, box, wslots);
+            return;
+        }
+    }
     const int64_t wave = remap_block() * kWavesPerBlock + wib;
     const int64_t e_wave = wave * EPW;             // first env of this wave (scalar)
-    if (e_wave >= n_envs) return;                  // whole wave idle
+    if (e_wave >= n_envs) return;                  // whole wave idle (a finished wave no longer counts at the barrier)
     const int D = 5 + 3 * N;
     const int n_rows = (int)((n_envs - e_wave) < EPW ? (n_envs - e_wave) : EPW);
     const bool active = el < n_rows;               // whole groups are active or not
-    const State<T> s = rebase(s_arg, e_wave, N);   // everything below indexes envs by `el`
+    State<T> s_in = s_arg;
+    // only the per-step auto-reset launch takes a second state generation (launch_step_impl); elsewhere the offsets are
+    // compile-time zeros and cost no registers
+    if constexpr (ROLLOUT || !AUTO_RESET) { s_in.w_env = 0; s_in.w_trf = 0; }
+    const State<T> s = rebase(s_in, e_wave, N);    // everything below indexes envs by `el`
     const StepIO<T> io0 = rebase(io_arg, e_wave, D);
-    extern __shared__ __align__(16) unsigned char lds_raw[];
     // per wave: the observation tile, then (HANDOFF) the reset slots (SlotLayout) / one 4N+1-value scratch
     constexpr bool HANDOFF = PACKED && AUTO_RESET;   // finished envs are reset BEFORE the wave's stores
     T* tile = reinterpret_cast<T*>(lds_raw) + wib * tile_elems;
@@ -1410,13 +1640,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
         if constexpr (!POLICY) action_next = io0.actions[el_l];
         if constexpr (PACKED) tr = load_traffic<T, C>(s, el_l * N + j * C);
     }
+    // The worker has cleared the mailbox before it joins this barrier.  (inline asm: behind the intrinsic hipcc puts
+    // s_waitcnt vmcnt(0) lgkmcnt(0) in front of every barrier on this target -- the loads above would have to land here)
+    if constexpr (WORKER) asm volatile("s_barrier" ::: "memory");
 
     // Launch constants into VGPRs only now, AFTER the loads are in flight: pinned() is ~25 v_movs
     // behind a kernarg s_load round trip, which used to sit in front of the first global load.
     // (not for the policy rollout: its MLP needs the 25 registers more than it minds re-fetching
     // launch constants, and has to stay under 256 VGPRs to keep two waves per SIMD)
     const Params<T> p = POLICY ? p_arg : pinned(p_arg);
-    if constexpr (AUTO_RESET && !ROLLOUT) {
+    if constexpr (AUTO_RESET && !ROLLOUT && !WORKER) {
         // ... and what the reset of a finished env reads, so that its wave does not start the reset
         // with a scalar-load round trip (the kernel ends with that wave)
         asm volatile("" :: "s"(rp.own_x0), "s"(rp.own_y0), "s"(rp.own_v), "s"(rp.own_heading0), "s"(rp.own_heading_jitter),
@@ -1442,6 +1675,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                            io0.ep_steps ? io0.ep_steps + te : nullptr};
         const bool last = !ROLLOUT || t == T_steps - 1;
         uint8_t oc = 0;
+        unsigned long long dm_posted = 0;                      // worker shapes: what outcome_known() posted ...
+        uint32_t req_no = 0;                                   // ... and the request number of the lane's env
         T action = action_next;
         if constexpr (POLICY) {
             constexpr int DP = 5 + 3 * NS;                // compile-time obs width (packed shapes)
@@ -1512,8 +1747,24 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             auto before_traffic = [&](const OwnCtx<T>&) {
                 if constexpr (!AUTO_RESET) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); }
             };
+            // Worker shapes: the step's outcome is decided here -- post the finishing envs, the worker draws their next
+            // episodes while this wave completes the observation and the reward (see reset_worker()).
+            auto outcome_known = [&](T d_goal, int collided) {
+                if constexpr (WORKER) {
+                    const bool fin_e = active && ((steps > p.max_steps) || collided != 0 || d_goal < p.goal_radius) && j == 0;
+                    dm_posted = __ballot(fin_e);
+                    if (dm_posted != 0ull) {                          // (wave-uniform; rare)
+                        uint32_t base = 0u;
+                        if (lane == 0) base = lds_add(&box->n_req, (uint32_t)__popcll(dm_posted));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        req_no = base + (uint32_t)__popcll(dm_posted & ((1ull << lane) - 1ull));
+                        if (fin_e) { lds_poke(&box->list[req_no][0], ((uint32_t)wib << 16) | (uint32_t)el); lds_poke(&box->list[req_no][1], episode); }
+                    }
+                    if (lane == 0) (void)lds_add(&box->posted, 1u);
+                }
+            };
             Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
-                                                       ROLLOUT ? &trig : nullptr, before_traffic);
+                                                       ROLLOUT ? &trig : nullptr, before_traffic, outcome_known);
 
             // game.py:249-292 evaluate()
             T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
@@ -1537,9 +1788,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                 io.outcome[el] = oc;
                 if constexpr (!HANDOFF) {
                     if (last && (oc == 0 || !AUTO_RESET)) {
-                        s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
-                        s.steps[el] = steps;
-                        s.total_reward[el] = total;
+                        put_env(s, s.own_x, el, o.x); put_env(s, s.own_y, el, o.y); put_env(s, s.own_psi, el, o.psi);
+                        put_env(s, s.steps, el, steps);
+                        put_env(s, s.total_reward, el, total);
                         if constexpr (!AUTO_RESET) { if (oc) s.status[el] = oc; }
                     }
                 }
@@ -1558,7 +1809,52 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             bool fresh = false, same_consts = false;
             unsigned long long dm = __ballot(oc != 0 && j == 0);
             constexpr bool SLOTTED = ResetSlots<NS>::SLOTS >= 2;      // N + 1 <= 32: several envs per pass
-            if constexpr (SLOTTED) {
+            if constexpr (WORKER) {
+                // ---- the worker wave drew the new episodes (reset_worker()): commit them, one finished env after the other
+                //      (dm == dm_posted: the same steps / distances / d_goal decide both) ----
+                using RS = ResetSlots<NS>;
+                using WS = WorkerSlot<T, NS>;
+                using SL = SlotLayout<T, NS>;
+                while (dm) {
+                    const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);   // wave-uniform
+                    dm &= dm - 1ull;
+                    const uint32_t r = (uint32_t)lane_value((int)req_no, src);
+                    while (lds_peek_s(&box->served) <= r / RS::SLOTS) __builtin_amdgcn_s_sleep(1);
+                    const int e_s = src / G;
+                    T* row_s = tile + e_s * D;
+                    const T* scr = wslots + (r % RS::SLOTS) * WS::STRIDE;
+                    const T* frow = scr + WS::ROW;
+                    wave_lds_fence();                     // every row of the tile is complete
+                    // the finished row to term_obs, the fresh row into the tile
+                    for (int i = lane; i < D; i += 64) {
+                        const T old = row_s[i], fresh_v = frow[i];
+                        if (io.term_obs) (io.term_obs + e_s * D)[i] = old;
+                        row_s[i] = fresh_v;
+                    }
+                    if (el == e_s) {                      // the owner group goes on with the new episode
+                        if (j == 0) {
+                            if (io.ep_return) io.ep_return[el] = total;
+                            if (io.ep_steps) io.ep_steps[el] = steps;
+                        }
+                        using V = Vec<T, C>;              // the slot's blocks are aligned like the live traffic block
+                        tr.x = *reinterpret_cast<const V*>(scr + j * C);
+                        tr.y = *reinterpret_cast<const V*>(scr + N + j * C);
+                        tr.psi = *reinterpret_cast<const V*>(scr + 2 * N + j * C);
+                        tr.v = *reinterpret_cast<const V*>(scr + 3 * N + j * C);
+                        same_consts = o.v == (T)rp.own_v && o.gx == (T)rp.goal_x && o.gy == (T)rp.goal_y;
+                        o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, scr[SL::OWN_PSI], (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
+                        steps = 1;                                            // environment.py:47
+                        total = T(0);
+                        episode += 1u;
+                        fresh = true;
+                        const int i0 = el * N + j * C;
+                        put_trf<T, C>(s, s.trf_x, i0, tr.x); put_trf<T, C>(s, s.trf_y, i0, tr.y);
+                        *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
+                    }
+                    wave_lds_fence();                     // the slot has been read ...
+                    if (lane == 0) (void)lds_add(&box->consumed, 1u);     // ... (DS operations execute in order) and may be reused
+                }
+            } else if constexpr (SLOTTED) {
                 using SL = SlotLayout<T, NS>;
                 while (dm) {
                     wave_lds_fence();                     // every row of the tile is complete
@@ -1588,7 +1884,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                         fresh = true;
                         trig.valid = false; trig.dirty = false;   // new headings (stored below)
                         const int i0 = el * N + j * C;
-                        *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+                        put_trf<T, C>(s, s.trf_x, i0, tr.x); put_trf<T, C>(s, s.trf_y, i0, tr.y);
                         *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
                     }
                     wave_lds_fence();                     // the slots are free for the next pass
@@ -1623,7 +1919,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                     // the new traffic block: whole 16-byte vectors from the owner lanes
                     using V = Vec<T, C>;
                     const int i0 = el * N + j * C;
-                    *reinterpret_cast<V*>(s.trf_x + i0) = tr.x; *reinterpret_cast<V*>(s.trf_y + i0) = tr.y;
+                    put_trf<T, C>(s, s.trf_x, i0, tr.x); put_trf<T, C>(s, s.trf_y, i0, tr.y);
                     *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
                 }
                 wave_lds_fence();                         // scratch is free for the next finished env
@@ -1634,9 +1930,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                     if (!same_consts) { s.own_v[el] = o.v; s.goal_x[el] = o.gx; s.goal_y[el] = o.gy; }
                 }
                 if (last || fresh) {
-                    s.own_x[el] = o.x; s.own_y[el] = o.y; s.own_psi[el] = o.psi;
-                    s.steps[el] = steps;
-                    s.total_reward[el] = total;
+                    put_env(s, s.own_x, el, o.x); put_env(s, s.own_y, el, o.y); put_env(s, s.own_psi, el, o.psi);
+                    put_env(s, s.steps, el, steps);
+                    put_env(s, s.total_reward, el, total);
                 }
             }
         }
@@ -1733,7 +2029,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(Params<T> p_arg, StepRese
 struct Shape { int C, G; bool packed; };
 Shape choose_shape(int n_traffic, int elem_size);
 template <typename T>
-int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, uint32_t flags,
+int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dState* st_out, const Acas2dStepIO* io, uint32_t flags,
                 uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream);
 template <typename T>
 int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, int32_t n_steps,

@@ -46,12 +46,51 @@ template <typename T>
 static State<T> make_state(const Acas2dState& s) {
     return State<T>{(T*)s.own_x, (T*)s.own_y, (T*)s.own_psi, (T*)s.own_v, (T*)s.goal_x, (T*)s.goal_y,
                     (T*)s.trf_x, (T*)s.trf_y, (T*)s.trf_psi, (T*)s.trf_v, s.steps,
-                    (T*)s.total_reward, s.status, s.episode, (T*)s.trace};
+                    (T*)s.total_reward, s.status, s.episode, (T*)s.trace, 0, 0};
 }
 
 static bool state_complete(const Acas2dState* s) {
     return s && s->own_x && s->own_y && s->own_psi && s->own_v && s->goal_x && s->goal_y && s->trf_x &&
            s->trf_y && s->trf_psi && s->trf_v && s->steps && s->total_reward && s->status && s->episode;
+}
+
+// Double-buffered state (acas2d_step_* with a state_out): the element offsets of `out`'s per-step arrays from
+// `st`'s -- own_x, own_y, own_psi, steps, total_reward share one (w_env), trf_x and trf_y another (w_trf); e.g.
+// every such array allocated as [2][E] / [2][E][N] and the two structs pointing at its two halves.  Everything
+// else must be the same buffer in both structs (those arrays change at a reset only, in place).
+template <typename T>
+static int write_offsets(const Acas2dState* st, const Acas2dState* out, bool auto_reset, int64_t n_envs, int n_traffic,
+                         int32_t* w_env, int32_t* w_trf) {
+    *w_env = 0; *w_trf = 0;
+    if (!out || out == st) return ACAS2D_OK;
+    if (!state_complete(out)) { set_error("acas2d_step: state_out has a NULL buffer"); return ACAS2D_EINVAL; }
+    if (out->own_v != st->own_v || out->goal_x != st->goal_x || out->goal_y != st->goal_y || out->trf_psi != st->trf_psi ||
+        out->trf_v != st->trf_v || out->status != st->status || out->episode != st->episode || out->trace != st->trace) {
+        set_error("acas2d_step: state_out must share own_v, goal_x, goal_y, trf_psi, trf_v, status, episode and trace with state "
+                  "(only own_x, own_y, own_psi, steps, total_reward, trf_x, trf_y are double-buffered)");
+        return ACAS2D_EINVAL;
+    }
+    const int64_t d = (const T*)out->own_x - (const T*)st->own_x, dt = (const T*)out->trf_x - (const T*)st->trf_x;
+    if ((const T*)out->own_y - (const T*)st->own_y != d || (const T*)out->own_psi - (const T*)st->own_psi != d ||
+        (const T*)out->total_reward - (const T*)st->total_reward != d || out->steps - st->steps != d ||
+        (const T*)out->trf_y - (const T*)st->trf_y != dt) {
+        set_error("acas2d_step: state_out's own_x, own_y, own_psi, steps, total_reward must lie at ONE element offset from "
+                  "state's, trf_x and trf_y at one (e.g. each array allocated [2][E] / [2][E][N])");
+        return ACAS2D_EINVAL;
+    }
+    if (d == 0 && dt == 0) return ACAS2D_OK;
+    if (!auto_reset) {
+        set_error("acas2d_step: a separate state_out needs ACAS2D_AUTO_RESET (the latching step leaves frozen traffic unwritten)");
+        return ACAS2D_EINVAL;
+    }
+    const int64_t lim = 0x7fffffffLL - n_envs * (int64_t)n_traffic - 64;
+    const int64_t ad = d < 0 ? -d : d, adt = dt < 0 ? -dt : dt;
+    if (ad < n_envs || adt < n_envs * (int64_t)n_traffic || ad > lim || adt > lim) {
+        set_error("acas2d_step: state_out overlaps state, or lies more than 2^31 elements away");
+        return ACAS2D_EINVAL;
+    }
+    *w_env = (int32_t)d; *w_trf = (int32_t)dt;
+    return ACAS2D_OK;
 }
 
 static int check_launch(const char* what) {
@@ -62,10 +101,20 @@ static int check_launch(const char* what) {
 
 // Launch geometry for a shape: one env per G lanes, 64 / G envs per wavefront, 4 wavefronts per
 // workgroup, one LDS observation tile per wavefront.
-struct Geometry { unsigned grid; int tile_elems; size_t lds_bytes; };
+struct Geometry { unsigned grid, block; int tile_elems; size_t lds_bytes; };
+
+// The per-step auto-reset launch of a packed shape with N + 1 <= 32 runs with a fifth wavefront per workgroup, the
+// reset worker (acas2d_kernels.hpp, reset_worker(); UsesWorker<> there is this predicate at compile time).
+static bool worker_shape(const Shape& sh, int n_traffic) {
+#ifdef ACAS2D_NO_WORKER
+    return false;
+#else
+    return sh.packed && n_traffic + 1 <= 32 && kWavesPerBlock == 4;
+#endif
+}
 
 template <typename T>
-static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g) {
+static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g, bool worker = false) {
     const int64_t epw = 64 / sh.G, envs_per_block = epw * kWavesPerBlock;
     const int64_t blocks = (n_envs + envs_per_block - 1) / envs_per_block;
     if (blocks > 0x7fffffffLL) { set_error("n_envs = %lld exceeds the grid limit", (long long)n_envs); return ACAS2D_EINVAL; }
@@ -73,20 +122,24 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
     // per wave: the observation tile, then the reset slots (SlotLayout<T, N> in the kernels; packed shapes with
     // N + 1 <= 32) or one 4N+1-value hand-off scratch (the other packed shapes), everything 16-byte aligned
     const int64_t tile = (epw * (5 + 3 * (int64_t)n_traffic) + 3) / 4 * 4;
-    int64_t scratch = 0;
+    int64_t scratch = 0, shared = 0;
     if (sh.packed && n_traffic + 1 <= 32) {
         int stride = 2; while (stride < n_traffic + 1) stride *= 2;
-        scratch = (64 / stride) * ((4 * (int64_t)n_traffic + 1 + W - 1) / W * W);
+        const int64_t state = (4 * (int64_t)n_traffic + 1 + W - 1) / W * W;
+        if (worker)      // the workgroup's mailbox and slots (WorkerBox / WorkerSlot) behind the four tiles, no per-wave scratch
+            shared = (int64_t)sizeof(WorkerBox) + (64 / stride) * (state + (5 + 3 * (int64_t)n_traffic + W - 1) / W * W) * (int64_t)sizeof(T);
+        else
+            scratch = (64 / stride) * state;
     } else if (sh.packed) {
         scratch = 4 * (int64_t)n_traffic + 1;
     }
     const int64_t elems = ((tile + scratch + 3) / 4) * 4;
-    const int64_t bytes = elems * kWavesPerBlock * (int64_t)sizeof(T);
+    const int64_t bytes = elems * kWavesPerBlock * (int64_t)sizeof(T) + shared;
     if (bytes > 64 * 1024) {
         set_error("n_traffic = %d needs a %lld-byte LDS observation tile per workgroup (limit 65536)", n_traffic, (long long)bytes);
         return ACAS2D_EINVAL;
     }
-    g->grid = (unsigned)blocks; g->tile_elems = (int)elems; g->lds_bytes = (size_t)bytes;
+    g->grid = (unsigned)blocks; g->block = (unsigned)(kBlock + (worker ? 64 : 0)); g->tile_elems = (int)elems; g->lds_bytes = (size_t)bytes;
     return ACAS2D_OK;
 }
 
@@ -95,10 +148,10 @@ static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, c
                        const ResetParamsT<T>& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
                        int64_t env_offset, int64_t n_envs, int N) {
     if (auto_reset)
-        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, FAST, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, FAST, false>), dim3(g.grid), dim3(g.block), g.lds_bytes, stream,
                            p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
     else
-        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, FAST, false>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
+        hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, FAST, false>), dim3(g.grid), dim3(g.block), g.lds_bytes, stream,
                            p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
 }
 
@@ -159,8 +212,8 @@ static int resolve_shape(int n_traffic, Shape* out) {
 }
 
 template <typename T, bool FAST>
-static int launch_step_impl(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io_, uint32_t flags,
-                uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
+static int launch_step_impl(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dState* st_out, const Acas2dStepIO* io_,
+                uint32_t flags, uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
     if (!cfg || !io_) { set_error("acas2d_step: NULL cfg / io"); return ACAS2D_EINVAL; }
     if (!state_complete(st)) { set_error("acas2d_step: NULL state or a NULL state buffer"); return ACAS2D_EINVAL; }
     if (!io_->actions || !io_->obs || !io_->reward || !io_->done || !io_->outcome) {
@@ -170,15 +223,16 @@ static int launch_step_impl(const Acas2dConfig* cfg, const Acas2dState* st, cons
     if (n_envs == 0) return ACAS2D_OK;
     Shape sh;
     if (int rc = resolve_shape<T>(n_traffic, &sh)) return rc;
+    const bool ar = (flags & ACAS2D_AUTO_RESET) != 0;
     Geometry g;
-    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
+    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g, ar && worker_shape(sh, n_traffic))) return rc;
     const Params<T> p = make_params<T>(*cfg);
     const ResetParamsT<T> rp = make_reset_params<T>(*cfg);
-    const State<T> s = make_state<T>(*st);
+    State<T> s = make_state<T>(*st);
+    if (int rc = write_offsets<T>(st, st_out, ar, n_envs, n_traffic, &s.w_env, &s.w_trf)) return rc;
     const StepIO<T> io{(const T*)io_->actions, (T*)io_->obs, (T*)io_->reward, io_->done, io_->outcome,
                        (T*)io_->term_obs, (T*)io_->ep_return, io_->ep_steps};
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    const bool ar = (flags & ACAS2D_AUTO_RESET) != 0;
     if (sh.packed) {
 #define X(C_, G_) if (sh.C == C_ && sh.G == G_) step_shape<T, FAST, C_, G_, true>(ar, g, stream, p, rp, s, io, k0, k1, env_offset, n_envs, n_traffic);
         ACAS2D_PACKED_SHAPES(X)
@@ -315,10 +369,10 @@ template <typename T>
 static bool fast_math(const Acas2dConfig* cfg) { return kFast || (cfg && cfg->math == ACAS2D_MATH_FAST); }
 
 template <typename T>
-int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, uint32_t flags,
+int launch_step(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dState* st_out, const Acas2dStepIO* io, uint32_t flags,
                 uint64_t seed, int64_t env_offset, int64_t n_envs, int32_t n_traffic, hipStream_t stream) {
-    return fast_math<T>(cfg) ? launch_step_impl<T, true>(cfg, st, io, flags, seed, env_offset, n_envs, n_traffic, stream)
-                             : launch_step_impl<T, kFast>(cfg, st, io, flags, seed, env_offset, n_envs, n_traffic, stream);
+    return fast_math<T>(cfg) ? launch_step_impl<T, true>(cfg, st, st_out, io, flags, seed, env_offset, n_envs, n_traffic, stream)
+                             : launch_step_impl<T, kFast>(cfg, st, st_out, io, flags, seed, env_offset, n_envs, n_traffic, stream);
 }
 template <typename T>
 int launch_rollout(const Acas2dConfig* cfg, const Acas2dState* st, const Acas2dStepIO* io, int32_t n_steps,

@@ -232,17 +232,38 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(Segments seg, int total
     if (tid == 0) step[0] = tstep;
 }
 
+// Dynamic LDS of ppo_grad_kernel<D>: 4 x 64 per-sample vectors with row stride 65, the observations, one scratch row
+// (69.6 - 74.8 KB for D = 8 ... 29).  More than the 64 KB a HIP launch gets without asking: the attribute below raises
+// the kernel's limit, and the size is checked against what the device reports (gfx950: 160 KB per workgroup).
 template <int D>
-void launch_grad(const Acas2dPpoUpdate& u, hipStream_t stream) {
+int launch_grad(const Acas2dPpoUpdate& u, hipStream_t stream) {
     const NetW a{(const float*)u.actor_w1, (const float*)u.actor_b1, (const float*)u.actor_w2, (const float*)u.actor_b2,
                  (const float*)u.actor_w3, (const float*)u.actor_b3};
     const NetW c{(const float*)u.critic_w1, (const float*)u.critic_b1, (const float*)u.critic_w2, (const float*)u.critic_b2,
                  (const float*)u.critic_w3, (const float*)u.critic_b3};
     const size_t lds_bytes = (size_t)(4 * 64 * kRow + 64 * (D + 1) + 64) * sizeof(float);
+    static int lds_limit = -1;                               // per instantiation, set once
+    if (lds_limit < 0) {
+        int dev = 0, optin = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) {
+            set_error("acas2d_ppo_update: cannot query the device's LDS size"); return ACAS2D_EHIP; }
+        if ((size_t)optin >= lds_bytes)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_grad_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipGetLastError();
+        lds_limit = optin;
+    }
+    if ((size_t)lds_limit < lds_bytes) {
+        set_error("acas2d_ppo_update: the gradient kernel needs %zu bytes of LDS per workgroup, this device offers %d "
+                  "(built for gfx950's 160 KB)", lds_bytes, lds_limit);
+        return ACAS2D_EINVAL;
+    }
     hipLaunchKernelGGL((ppo_grad_kernel<D>), dim3((unsigned)((u.n_rows + 63) / 64), 2), dim3(64), lds_bytes, stream, a, c,
                        (const float*)u.log_std, (const float*)u.obs, (const float*)u.act, (const float*)u.old_logp,
                        (const float*)u.adv, (const float*)u.ret, (const int64_t*)u.idx, u.n_rows, u.clip_range, u.vf_coef,
                        (float*)u.grad, (float*)u.stats);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) { set_error("acas2d_ppo_update gradient launch: %s", hipGetErrorString(err)); return ACAS2D_EHIP; }
+    return ACAS2D_OK;
 }
 
 }  // namespace
@@ -261,14 +282,16 @@ extern "C" int acas2d_ppo_update_f32(const Acas2dPpoUpdate* u, void* stream_) {
     for (const void* p : need) if (!p) { set_error("acas2d_ppo_update: every pointer is required"); return ACAS2D_EINVAL; }
     if (u->n_rows < 2) { set_error("acas2d_ppo_update: n_rows = %d (the advantage normalisation needs 2)", u->n_rows); return ACAS2D_EINVAL; }
     const int D = u->obs_dim;
+    int rc;
     switch (D) {
-        case 8: launch_grad<8>(*u, stream); break;
-        case 11: launch_grad<11>(*u, stream); break;
-        case 14: launch_grad<14>(*u, stream); break;
-        case 17: launch_grad<17>(*u, stream); break;
-        case 29: launch_grad<29>(*u, stream); break;
+        case 8: rc = launch_grad<8>(*u, stream); break;
+        case 11: rc = launch_grad<11>(*u, stream); break;
+        case 14: rc = launch_grad<14>(*u, stream); break;
+        case 17: rc = launch_grad<17>(*u, stream); break;
+        case 29: rc = launch_grad<29>(*u, stream); break;
         default: set_error("acas2d_ppo_update: obs_dim = %d (built for n_traffic in {1, 2, 3, 4, 8})", D); return ACAS2D_EINVAL;
     }
+    if (rc != ACAS2D_OK) return rc;                      // (a failed gradient launch must not read as a zero gradient)
     if (u->max_grad_norm < 0.0f) return ACAS2D_OK;      // tests: the raw gradient stays in `grad`, nothing is applied
     Segments seg;
     float* ptrs[13] = {(float*)u->actor_w1, (float*)u->actor_b1, (float*)u->actor_w2, (float*)u->actor_b2, (float*)u->actor_w3,

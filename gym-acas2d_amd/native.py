@@ -8,7 +8,7 @@ from .config import CConfig
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libacas2d_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 AUTO_RESET = 1
 
@@ -96,8 +96,8 @@ def lib():
     for name in ("acas2d_step_f32", "acas2d_step_f64"):
         f = getattr(L, name)
         f.restype = C.c_int
-        f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.POINTER(CStepIO), C.c_uint32,
-                      C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+        f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.POINTER(CState), C.POINTER(CStepIO), C.c_uint32,
+                      C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]      # state_out may be None
     for name in ("acas2d_rollout_f32", "acas2d_rollout_f64"):
         f = getattr(L, name)
         f.restype = C.c_int

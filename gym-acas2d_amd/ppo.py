@@ -210,10 +210,23 @@ class PPOTrainer:
         if self.collector not in ("graphs", "fused", "eager") or (self.collector != "eager" and not self.use_graphs):
             raise ValueError("collector %r needs use_graphs" % (self.collector,))
         self._fused_out = None
+        if self.collector == "graphs" and getattr(venv, "double_buffer", False):
+            # ONE captured env step is replayed n_steps times: every replay must read what the previous one wrote,
+            # which the double-buffered step (read generation g, write 1 - g) does not give a single-step graph
+            venv.set_double_buffer(False)
         self.updater = updater or "graphs"
         if self.updater not in ("graphs", "fused") or (self.updater == "fused" and not self.use_graphs):
             raise ValueError("updater %r needs use_graphs" % (self.updater,))
         self._fused_update = None
+        # the hand-written launches exist for the observation widths / traffic counts below: say so HERE, not at the
+        # first collect() / update() of a run
+        f32 = getattr(venv, "dtype", torch.float32) == torch.float32
+        if self.collector == "fused" and venv.n_traffic not in ((1, 2, 3, 4, 8) if f32 else (1, 2, 3)):
+            raise ValueError("collector='fused' needs a thread-per-env work shape: n_traffic in {1, 2, 3, 4, 8} (float32) / "
+                             "{1, 2, 3} (float64), got %d -- use collector='graphs'" % venv.n_traffic)
+        if self.updater == "fused" and venv.obs_dim not in (8, 11, 14, 17, 29):
+            raise ValueError("updater='fused' is built for obs_dim in {8, 11, 14, 17, 29} (n_traffic 1, 2, 3, 4, 8), got %d "
+                             "-- use updater='graphs'" % venv.obs_dim)
         # (fused: one multi-tensor kernel for the 13 parameter tensors instead of ~10 foreach launches)
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5,
                                     capturable=self.use_graphs, **({"fused": True} if self.use_graphs else {}))
@@ -296,7 +309,9 @@ class PPOTrainer:
         n = self.cfg.n_steps * self.venv.num_envs
         B = min(self.cfg.batch_size, n)
         self.mb_idx = torch.zeros(B, dtype=torch.int64, device=self.device)
-        self.mb_tail = torch.zeros(n % B, dtype=torch.int64, device=self.device) if n % B else None
+        # the partial last minibatch of an epoch, as SB3 takes it -- unless it is ONE row: the advantage normalisation
+        # divides by the standard deviation of the minibatch, which one row does not have (NaN in SB3 as well)
+        self.mb_tail = torch.zeros(n % B, dtype=torch.int64, device=self.device) if n % B > 1 else None
         env_before = self.venv.state_dict()
         obs_before, env_obs_before = self.obs.clone(), self.venv.outputs["obs"].clone()
         params_before = [p.detach().clone() for p in self.policy.parameters()]
@@ -440,6 +455,8 @@ class PPOTrainer:
             perm = torch.randperm(n, device=self.device)
             for i in range(0, n, cfg.batch_size):
                 idx = perm[i:i + cfg.batch_size]
+                if idx.numel() < 2:
+                    continue                              # a one-row tail has no advantage standard deviation
                 loss, pg, vf = ppo_loss(self.policy, cfg, obs[idx], act[idx], old_logp[idx], adv[idx], ret[idx])
                 self.opt.zero_grad(set_to_none=True)
                 loss.backward()
@@ -447,6 +464,17 @@ class PPOTrainer:
                 self.opt.step()
             stats = {"pg_loss": pg.item(), "value_loss": vf.item(), "std": self.policy.log_std.detach().exp().item()}
         return stats
+
+    def optimizer_state(self):
+        """The Adam state that is actually being stepped: with updater='fused' the moments live in FusedUpdate's
+        flat buffers (layout: actor w1 b1 w2 b2 w3 b3, critic likewise, log_std -- include/acas2d.h) and `self.opt`
+        is never stepped; otherwise `self.opt.state_dict()`."""
+        if self.updater == "fused" and self.use_graphs:
+            fu = self._fused_update
+            if fu is None:
+                return {"updater": "fused", "step": 0, "exp_avg": None, "exp_avg_sq": None}
+            return {"updater": "fused", "step": int(fu.step_count.item()), "exp_avg": fu.m, "exp_avg_sq": fu.v}
+        return {"updater": self.updater, **self.opt.state_dict()}
 
     def recent_episodes(self, clear=True):
         if not self.ep_returns:

@@ -39,6 +39,8 @@ class Scene:
     episode: int = 0
     total_reward: float = 0.0
     hud: dict = field(default_factory=dict)         # name -> value: the metrics / sub-rewards text of game.py:349-425
+    acc_lat_limit: float = 196.133                  # ACC_LAT_LIMIT = 20 g (settings.py:42): the a_lat_norm line
+    dt: float = 0.01                                # 1 / FPS (aircraft.py:18): the psi_dot line
 
     @classmethod
     def from_env(cls, env, index=0):
@@ -58,18 +60,23 @@ class Scene:
                    goal=(host(vec.goal_x), host(vec.goal_y)), collision_radius=float(cfg.collision_radius),
                    goal_radius=float(cfg.goal_radius), steps=int(vec.steps[i].item()),
                    episode=int(getattr(game, "episode", None) or vec.episode[i].item()),
-                   total_reward=host(vec.total_reward), hud=hud)
+                   total_reward=host(vec.total_reward), hud=hud, acc_lat_limit=float(cfg.acc_lat_limit),
+                   dt=float(cfg.dt))
 
     def text_lines(self):
         """The HUD as (x, y, text) in the reference's positions (game.py:349-404)."""
         px, py, psi, v = self.player
         h = self.hud
         left = [(20, 20, "pos: (%.1f, %.1f)" % (px, py)), (20, 40, "v_air: %.1f" % v), (20, 60, "psi: %.1f" % psi)]
-        if "a_lat" in h:
-            left.append((20, 100, "a_lat: %.1f" % h["a_lat"]))
+        if "a_lat" in h:                             # game.py:355-361: psi_dot = a_lat / (v_air dt) (aircraft.py:20)
+            left += [(20, 80, "psi_dot: %.1f" % (h["a_lat"] / (v * self.dt))), (20, 100, "a_lat: %.1f" % h["a_lat"]),
+                     (20, 120, "a_lat_norm: %.3f" % (h["a_lat"] / self.acc_lat_limit))]
         bottom = [("d_goal", "Distance to goal", 20), ("d_sep", "Min. Separation", 40), ("v_closing", "Closing Speed", 80),
                   ("d_cpa", "Closest approach", 100), ("delta_heading", "Delta heading", 120), ("d_dev", "Plan deviation", 140)]
         left += [(20, HEIGHT - dy, "%s: %.1f" % (label, h[k])) for k, label, dy in bottom if k in h]
+        if self.traffic:                             # game.py:369-372: relative_angle(player -> traffic[0]) (kinematics.py:16-22)
+            tx, ty = self.traffic[0][:2]
+            left.append((20, HEIGHT - 60, "Rel. angle to traffic: %.1f" % (np.degrees(np.arctan2(ty - py, tx - px) % (2 * np.pi)))))
         mid = [(WIDTH // 2 - 50, HEIGHT - 20, "Steps: %d" % self.steps), (WIDTH // 2 - 50, HEIGHT - 40, "Episode: %s" % self.episode)]
         right = [(WIDTH - 300, HEIGHT - 20, "Total reward: %.1f" % self.total_reward)]
         rewards = [("r_step", "Step reward", 40), ("r_d_dev", "Step plan deviation reward", 60),
@@ -159,16 +166,19 @@ class PygameWindow:
         for event in pg.event.get():
             if event.type == pg.QUIT:
                 self.open = False
+        # the reference's order (game.py:323-346): sky, player, goal, traffic, then the player's collision circle, the
+        # goal circle, the traffic's collision circles; glyphs stand in for its three 24 x 24 sprites
         self.screen.fill(SKY_RGB)
         gx, gy = scene.goal
+        px, py, ppsi, _ = scene.player
+        pg.draw.polygon(self.screen, PLAYER_RGB, _triangle(px, py, ppsi))
         pg.draw.rect(self.screen, GOAL_RGB, (gx - AIRCRAFT_SIZE / 2, gy - AIRCRAFT_SIZE / 2, AIRCRAFT_SIZE, AIRCRAFT_SIZE))
         for (x, y, psi, _v) in scene.traffic:
             pg.draw.polygon(self.screen, TRAFFIC_RGB, _triangle(x, y, psi))
-            pg.draw.circle(self.screen, RED_RGB, (x, y), scene.collision_radius, 1)
-        px, py, ppsi, _ = scene.player
-        pg.draw.polygon(self.screen, PLAYER_RGB, _triangle(px, py, ppsi))
         pg.draw.circle(self.screen, RED_RGB, (px, py), scene.collision_radius, 1)
         pg.draw.circle(self.screen, YELLOW_RGB, (gx, gy), scene.goal_radius, 1)
+        for (x, y, _psi, _v) in scene.traffic:
+            pg.draw.circle(self.screen, RED_RGB, (x, y), scene.collision_radius, 1)
         for x, y, text in scene.text_lines():
             self.screen.blit(self.font.render(text, True, BLACK_RGB), (x, y))
         pg.display.update()

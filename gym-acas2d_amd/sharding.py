@@ -4,7 +4,8 @@ Every env is independent (no cross-env reads anywhere in game.py / kinematics.py
 so the step path needs NO collective: rank r owns the contiguous block
 [offset, offset + count) of global env indices, resident on its GPU for the whole run, and the
 counter-based reset RNG is keyed on the GLOBAL index, so results do not depend on the sharding.
-The only optional exchange is gathering per-rank rollout statistics to rank 0, off the step path.
+The only optional exchanges are off the step path: gathering per-rank episode statistics, and gathering the
+rollout buffers of a collection ([T, E / world, ...] per rank) to a learner rank (`gather_rollout`).
 """
 import os
 
@@ -78,3 +79,51 @@ def gather_episode_stats(returns, lengths, dst=0):
         return None, None
     return ([r[:int(s.item())] for r, s in zip(out_r, sizes)],
             [l[:int(s.item())] for l, s in zip(out_l, sizes)])
+
+
+def gather_rollout(buffers, dst=0, total_envs=None):
+    """Optional, off the step path (BASELINE.json north star: "optional RCCL gather of rollout buffers only"):
+    gather the rollout buffers of one collection to the learner rank `dst`.
+
+    buffers      dict name -> tensor [T, E_rank, ...] -- what `ACAS2DVecEnv.rollout()` / `collect()` return (obs,
+                 actions, reward, done, values, ...); same T, trailing shape and dtype on every rank, E_rank = this
+                 rank's `shard_range` count (ranks may differ by one env).  Keys that start with "_" are skipped.
+    Returns      on `dst`: dict name -> [T, E_total, ...] with the envs in GLOBAL index order (rank r's block at
+                 `shard_range(total, r, world)`); None on the other ranks.
+
+    One `torch.distributed.gather` per buffer (bool buffers travel as uint8).  With backend "nccl" (RCCL) a gather
+    is grouped point-to-point sends into `dst`: on MI355X every sender uses its own xGMI link to the learner
+    (7 links x ~153 GB/s in parallel), where a ring all-gather would be bound by ONE link per hop and would deliver
+    the data to seven ranks that do not need it.  At BASELINE configs[3] (131 072 envs per GPU, N = 8, float32:
+    29 observation values + action + reward + done per env and step) one step of the whole shard is 16.8 MB per
+    GPU: ~0.11 ms on its link, against 10 us for the step itself -- which is why this is never on the step path
+    (gather a T-step collection once per PPO iteration, overlapped with the next collection)."""
+    names = [k for k in sorted(buffers) if not k.startswith("_") and torch.is_tensor(buffers[k])]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return {k: buffers[k] for k in names}
+    world, rank = dist.get_world_size(), dist.get_rank()
+    e_rank = int(buffers[names[0]].shape[1])
+    counts = [torch.zeros(1, dtype=torch.int64, device=buffers[names[0]].device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([e_rank], dtype=torch.int64, device=buffers[names[0]].device))
+    counts = [int(c.item()) for c in counts]
+    if total_envs is not None and sum(counts) != int(total_envs):
+        raise ValueError("gather_rollout: the shards hold %d envs, expected %d" % (sum(counts), total_envs))
+    e_max = max(counts)
+    out = {}
+    for k in names:
+        t = buffers[k]
+        if t.shape[1] != e_rank:
+            raise ValueError("gather_rollout: buffer %r has %d envs, %r has %d" % (k, t.shape[1], names[0], e_rank))
+        as_bool = t.dtype == torch.bool
+        src = t.view(torch.uint8) if as_bool else t
+        if e_rank != e_max:                      # ranks differ by at most one env: pad the short ones
+            pad = torch.zeros((src.shape[0], e_max) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+            pad[:, :e_rank] = src
+            src = pad
+        src = src.contiguous()
+        parts = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
+        dist.gather(src, parts, dst=dst)
+        if rank == dst:
+            full = torch.cat([p[:, :c] for p, c in zip(parts, counts)], dim=1)
+            out[k] = full.view(torch.bool) if as_bool else full
+    return out if rank == dst else None

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define ACAS2D_ABI_VERSION 5
+#define ACAS2D_ABI_VERSION 6
 
 /* error codes */
 #define ACAS2D_OK 0
@@ -56,7 +56,11 @@ extern "C" {
  *               the parity mode);
  *      FAST:    the FAST formulation in float64 arithmetic -- d_cpa and d_dev in their algebraic forms (no
  *               atan2 / atan / sin per aircraft), reciprocal multiplications, a range-limited sincos -- within
- *               1e-9 of the reference on every fixture (tests/test_gpu_parity.py), at more than twice the rate. */
+ *               1e-9 of the reference on every fixture (tests/test_gpu_parity.py), at more than twice the rate.
+ *               One documented difference: the SIGN of a d_cpa observation entry is unspecified where the
+ *               reference's relative velocity component v12x is an exact 0 (|v12x| < 1e-9: equal airspeeds with
+ *               parallel or mirror-image headings) -- kinematics.py:47 takes arctan(v12y / v12x), whose sign there
+ *               is a coin toss of libm's cos; the magnitude still agrees to 1e-9 and DEFAULT reproduces the sign. */
 #define ACAS2D_MATH_DEFAULT 0
 #define ACAS2D_MATH_FAST 1
 
@@ -146,13 +150,26 @@ const char *acas2d_last_error(void);  /* thread-local; valid until the next fail
  *   otherwise: status[e] latches the outcome; stepping a finished env keeps moving the player
  *     but freezes its traffic (game.py:243-245).
  * env_offset = global index of env 0 of this shard (results are invariant to the sharding).
+ *
+ * state_out (ABI 6): NULL or == state: the step updates `state` in place.  Otherwise DOUBLE-BUFFERED state: the
+ *   step reads `state` and writes the arrays it rewrites for every env -- own_x, own_y, own_psi, steps,
+ *   total_reward, trf_x, trf_y -- into state_out's buffers instead (the caller then passes the two structs the
+ *   other way round at the next step; results are bit-identical to stepping in place).  Why: a store that hits
+ *   a cache line its launch loaded stays dirty in the XCD's L2 until the write-back at the END of the kernel,
+ *   whereas stores to the other generation stream out during it (65 536 x 8 float32: 4.23 vs 4.65 us per launch).
+ *   Layout contract: state_out's own_x, own_y, own_psi, steps and total_reward lie at ONE element offset from
+ *   state's, its trf_x and trf_y at one (e.g. every such array allocated as [2][E] / [2][E][N], the two structs
+ *   pointing at the two halves), without overlap and less than 2^31 elements away; every other field (own_v,
+ *   goal_*, trf_psi, trf_v, status, episode, trace: changed at a reset only, in place) is the SAME buffer in
+ *   both structs.  Needs ACAS2D_AUTO_RESET.  A hipGraph that captures an odd number of steps must not be
+ *   replayed twice in a row (each replay would read the generation the previous one also read).
  */
-int acas2d_step_f32(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
-                    uint32_t flags, uint64_t seed, int64_t env_offset, int64_t n_envs,
-                    int32_t n_traffic, void *stream);
-int acas2d_step_f64(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dStepIO *io,
-                    uint32_t flags, uint64_t seed, int64_t env_offset, int64_t n_envs,
-                    int32_t n_traffic, void *stream);
+int acas2d_step_f32(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dState *state_out,
+                    const Acas2dStepIO *io, uint32_t flags, uint64_t seed, int64_t env_offset,
+                    int64_t n_envs, int32_t n_traffic, void *stream);
+int acas2d_step_f64(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dState *state_out,
+                    const Acas2dStepIO *io, uint32_t flags, uint64_t seed, int64_t env_offset,
+                    int64_t n_envs, int32_t n_traffic, void *stream);
 
 /*
  * acas2d_rollout_*: n_steps consecutive ACAS2DEnv.step() calls fused into ONE launch -- the inner
@@ -246,6 +263,10 @@ int acas2d_collect_f64(const Acas2dConfig *cfg, const Acas2dState *state, const 
  * the first call -- [2] gradient norm, [4] policy loss, [5] value loss of the last minibatch.
  * obs_dim in {8, 11, 14, 17, 29} (n_traffic 1, 2, 3, 4, 8).  max_grad_norm < 0 (tests): only the gradient is
  * computed and left in `grad` (actor w1 b1 w2 b2 w3 b3, critic likewise, log_std), nothing is applied.
+ * Run-to-run: the per-wave partial gradients are added to `grad` with float atomics, whose order is not fixed, so two
+ * runs of the same update agree to float32 rounding of the sums (~1e-7 relative), not bit for bit -- unlike the env
+ * kernels, which are bitwise deterministic.  The gradient kernel uses 70 - 75 KB of LDS per workgroup (gfx950 has 160 KB;
+ * checked against the device at the first call, ACAS2D_EINVAL where it does not fit).
  */
 typedef struct Acas2dPpoUpdate {
     void *actor_w1, *actor_b1, *actor_w2, *actor_b2, *actor_w3, *actor_b3;       /* mlp_extractor.policy_net.{0,2}, action_net */

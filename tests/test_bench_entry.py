@@ -58,10 +58,17 @@ def test_driver_style_torchrun_launch():
 
 
 def test_a_failing_rank_fails_the_launcher():
-    """The child's return code is handed back (here: an argument error inside the ranks)."""
+    """A rank that dies AFTER the rendezvous (ACAS2D_BENCH_FAIL_RANK, a test hook inside the ranks) takes the job down:
+    torchrun reports it, `python bench.py --gpus 2` hands the non-zero code back and prints no result line; the same
+    command without the hook succeeds (test_plain_invocation_with_gpus_2_starts_its_own_ranks)."""
+    env = dict(_env(), ACAS2D_BENCH_FAIL_RANK="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearsal", "--steps", "5", "--warmup", "1", "--envs", "64"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0 and not _json_lines(r.stdout)
+    # an argument the parent itself rejects never starts any rank
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearsal", "--dtype", "f16"],
                        capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
-    assert r.returncode != 0
+    assert r.returncode == 2
 
 
 def test_pick_chunk_and_repeats():

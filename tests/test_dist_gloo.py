@@ -52,6 +52,22 @@ def _worker(rank, world, port, total, n_traffic, steps, out_dir):
         assert torch.equal(lens[1], torch.arange(3))
     else:
         assert rets is None
+    # the optional gather of a collection's rollout buffers to the learner rank (off the step path)
+    T = 4
+    gidx = torch.arange(off, off + cnt, dtype=torch.float64)
+    roll = {"obs": torch.as_tensor(np.stack(obs[1:T + 1])),                          # [T, cnt, D]
+            "reward": gidx[None, :] + 1000.0 * torch.arange(T, dtype=torch.float64)[:, None],
+            "done": (gidx[None, :].long() + torch.arange(T)[:, None]) % 3 == 0, "_scratch": object()}
+    full = g.sharding.gather_rollout(roll, dst=1, total_envs=total)
+    if rank == 1:
+        assert sorted(full) == ["done", "obs", "reward"] and full["obs"].shape == (T, total, 5 + 3 * n_traffic)
+        assert full["done"].dtype == torch.bool
+        e = torch.arange(total, dtype=torch.float64)
+        assert torch.equal(full["reward"], e[None, :] + 1000.0 * torch.arange(T, dtype=torch.float64)[:, None])
+        assert torch.equal(full["done"], (e[None, :].long() + torch.arange(T)[:, None]) % 3 == 0)
+        np.save(os.path.join(out_dir, "gathered_obs.npy"), full["obs"].numpy())
+    else:
+        assert full is None
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), obs=np.stack(obs), t_max=t_max, n_sum=n_sum,
              done=done_total, own_psi=env.own_psi, episode=env.episode)
     dist.destroy_process_group()
@@ -75,6 +91,8 @@ def test_two_rank_sharding_equals_unsharded(tmp_path):
         obs.append(o.copy())
         done += n
     assert np.array_equal(np.concatenate([p["obs"] for p in parts], axis=1), np.stack(obs))
+    # the gathered rollout on the learner rank is the unsharded rollout, envs in global order
+    assert np.array_equal(np.load(tmp_path / "gathered_obs.npy"), np.stack(obs)[1:5])
     assert np.array_equal(np.concatenate([p["own_psi"] for p in parts]), ref.own_psi)
     assert np.array_equal(np.concatenate([p["episode"] for p in parts]), ref.episode)
     assert all(float(p["t_max"]) == 2.0 for p in parts)                  # MAX over ranks

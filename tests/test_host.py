@@ -75,7 +75,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol(g):
     for name in declared:
         assert hasattr(L, name), name
     assert set(g.native.EXPORTS) == declared
-    assert L.acas2d_abi_version() == g.native.ABI_VERSION == 5 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
+    assert L.acas2d_abi_version() == g.native.ABI_VERSION == 6 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
     assert int(re.search(r"#define ACAS2D_ABI_VERSION (\d+)", header).group(1)) == g.native.ABI_VERSION
 
 
@@ -83,19 +83,44 @@ def test_c_abi_argument_validation_needs_no_gpu(g):
     L = g.native.lib()
     cfg = g.ACAS2DConfig().to_c()
     st, io = g.native.CState(), g.native.CStepIO()
-    assert L.acas2d_step_f32(None, C.byref(st), C.byref(io), 0, 0, 0, 4, 1, None) == -22
+    assert L.acas2d_step_f32(None, C.byref(st), None, C.byref(io), 0, 0, 0, 4, 1, None) == -22
     assert b"NULL cfg" in L.acas2d_last_error()
-    assert L.acas2d_step_f64(C.byref(cfg), C.byref(st), C.byref(io), 0, 0, 0, 4, 1, None) == -22
+    assert L.acas2d_step_f64(C.byref(cfg), C.byref(st), None, C.byref(io), 0, 0, 0, 4, 1, None) == -22
     assert b"state" in L.acas2d_last_error()
-    dummy = (C.c_double * 64)()
-    full = g.native.CState(*([C.addressof(dummy)] * 14))        # trace stays NULL
-    assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), C.byref(io), 0, 0, 0, 4, 1, None) == -22
+    dummy = (C.c_double * 4096)()
+    base = C.addressof(dummy)
+    full = g.native.CState(*([base] * 14))        # trace stays NULL
+    assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), None, C.byref(io), 0, 0, 0, 4, 1, None) == -22
     assert b"required" in L.acas2d_last_error()
-    io_ok = g.native.CStepIO(*([C.addressof(dummy)] * 5 + [None] * 3))
-    assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), C.byref(io_ok), 0, 0, 0, 4, 0, None) == -22
+    io_ok = g.native.CStepIO(*([base] * 5 + [None] * 3))
+    assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), None, C.byref(io_ok), 0, 0, 0, 4, 0, None) == -22
     assert b"n_traffic" in L.acas2d_last_error()
-    assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), C.byref(io_ok), 0, 0, 0, -1, 1, None) == -22
-    assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), C.byref(io_ok), 0, 0, 0, 0, 1, None) == 0   # no-op
+    assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), None, C.byref(io_ok), 0, 0, 0, -1, 1, None) == -22
+    assert L.acas2d_step_f64(C.byref(cfg), C.byref(full), None, C.byref(io_ok), 0, 0, 0, 0, 1, None) == 0   # no-op
+    # state_out (double-buffered state, ABI 6): the layout contract of include/acas2d.h is checked before any launch
+    E, N, AR = 4, 2, g.native.AUTO_RESET
+
+    def gen2(**over):
+        """A second generation E (per-env arrays) / E * N (traffic arrays) elements behind `full`'s, in doubles."""
+        f = {n: getattr(full, n) for n, _ in g.native.CState._fields_}
+        for n in ("own_x", "own_y", "own_psi", "total_reward"):
+            f[n] = base + 8 * E
+        f["steps"] = base + 4 * E
+        f["trf_x"] = f["trf_y"] = base + 8 * E * N
+        f.update(over)
+        return g.native.CState(*[f[n] for n, _ in g.native.CState._fields_])
+
+    def step(out, flags=AR):
+        return L.acas2d_step_f64(C.byref(cfg), C.byref(full), None if out is None else C.byref(out), C.byref(io_ok), flags,
+                                 0, 0, E, N, None)
+
+    assert step(gen2(own_v=base + 64)) == -22 and b"must share" in L.acas2d_last_error()
+    assert step(gen2(own_y=base + 8 * (E + 1))) == -22 and b"ONE element offset" in L.acas2d_last_error()
+    assert step(gen2(steps=base + 8 * E)) == -22 and b"ONE element offset" in L.acas2d_last_error()
+    assert step(gen2(trf_y=base + 8 * E * N + 8)) == -22 and b"ONE element offset" in L.acas2d_last_error()
+    assert step(gen2(), flags=0) == -22 and b"ACAS2D_AUTO_RESET" in L.acas2d_last_error()
+    near = {n: base + 8 * (E - 1) for n in ("own_x", "own_y", "own_psi", "total_reward")}
+    assert step(gen2(steps=base + 4 * (E - 1), **near)) == -22 and b"overlaps" in L.acas2d_last_error()
     assert L.acas2d_reset_f32(C.byref(cfg), C.byref(st), None, None, 1, 0, 0, 4, 1, None) == -22
     assert L.acas2d_reset_f32(C.byref(cfg), C.byref(full), None, None, 1, 0, 0, 0, 1, None) == 0
     with pytest.raises(RuntimeError, match="acas2d: error -22"):

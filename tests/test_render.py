@@ -70,6 +70,112 @@ def test_pygame_is_imported_only_on_demand(monkeypatch):
     assert asked == ["pygame"]
 
 
+class _RecordingPygame:
+    """A stand-in for the `pygame` module that RECORDS every call (the image has no pygame; like the inert stand-ins
+    of oracle/refharness/stubs.py it contributes nothing but a surface to draw on)."""
+    QUIT = 256
+
+    def __init__(self, events=()):
+        import types
+        self.calls, self._events = [], list(events)
+        rec = self.calls.append
+        mod = self
+
+        class Surface:
+            def fill(self, rgb):
+                rec(("fill", tuple(rgb)))
+
+            def blit(self, src, pos):
+                rec(("blit", src, tuple(pos)))
+
+        class Font:
+            def __init__(self, name, size):
+                rec(("font", name, size))
+
+            def render(self, text, antialias, rgb):
+                return ("text", text, bool(antialias), tuple(rgb))
+
+        self.display = types.SimpleNamespace(set_mode=lambda size: (rec(("set_mode", tuple(size))), Surface())[1],
+                                             set_caption=lambda c: rec(("caption", c)),
+                                             update=lambda: rec(("update",)), quit=lambda: rec(("display.quit",)))
+        self.font = types.SimpleNamespace(Font=Font)
+        self.event = types.SimpleNamespace(get=lambda: [types.SimpleNamespace(type=t) for t in mod._pop_events()])
+        self.draw = types.SimpleNamespace(
+            rect=lambda surf, rgb, r: rec(("rect", tuple(rgb), tuple(float(v) for v in r))),
+            polygon=lambda surf, rgb, pts: rec(("polygon", tuple(rgb), [tuple(map(float, q)) for q in pts])),
+            circle=lambda surf, rgb, c, r, w=0: rec(("circle", tuple(rgb), tuple(map(float, c)), float(r), w)))
+
+    def init(self):
+        self.calls.append(("init",))
+
+    def _pop_events(self):
+        ev, self._events = self._events, []
+        return ev
+
+
+def test_pygame_window_draws_the_reference_frame(monkeypatch):
+    """PygameWindow.draw against a recording stand-in for pygame: the call sequence of ACAS2DGame.view()
+    (game.py:316-431) -- events, fill, player, goal, traffic, the player's collision circle, the goal circle, the
+    traffic's collision circles, the HUD text at the reference's positions, display.update -- with its radii and
+    colours, and the QUIT event that sets the `quit` flag (game.py:318-321)."""
+    import sys
+    fake = _RecordingPygame()
+    monkeypatch.setitem(sys.modules, "pygame", fake)
+    win = R.PygameWindow()
+    assert fake.calls[:3] == [("init",), ("set_mode", (1600, 1000)), ("caption", "ACAS-2D")]        # game.py:12-25
+    del fake.calls[:]
+    sc = _scene()
+    assert win.draw(sc) is True
+    kinds = [c[0] for c in fake.calls]
+    n_text = len(sc.text_lines())
+    assert kinds == ["fill", "polygon", "rect", "polygon", "polygon", "circle", "circle", "circle", "circle"] + ["blit"] * n_text + ["update"]
+    assert fake.calls[0] == ("fill", R.SKY_RGB)                                                       # game.py:324
+    # sprites' places: the player, the goal (a 24 x 24 square centred on it), the two traffic aircraft   (:327-337)
+    assert fake.calls[1][1] == R.PLAYER_RGB and fake.calls[2] == ("rect", R.GOAL_RGB, (1456 - 12.0, 500 - 12.0, 24.0, 24.0))
+    assert fake.calls[3][1] == fake.calls[4][1] == R.TRAFFIC_RGB
+    for call, (x, y) in zip((fake.calls[1], fake.calls[3], fake.calls[4]), ((400, 500), (900, 300), (1200, 800))):
+        cx, cy = np.mean(call[2], axis=0)
+        assert abs(cx - x) < 5 and abs(cy - y) < 5                           # the glyph sits on the aircraft
+    # circles: COLLISION_RADIUS 48 red around the player, GOAL_RADIUS 144 yellow, 48 red around each traffic, 1 px wide
+    assert fake.calls[5] == ("circle", R.RED_RGB, (400.0, 500.0), 48.0, 1)                            # game.py:340
+    assert fake.calls[6] == ("circle", R.YELLOW_RGB, (1456.0, 500.0), 144.0, 1)                       # :343-344
+    assert fake.calls[7] == ("circle", R.RED_RGB, (900.0, 300.0), 48.0, 1) and fake.calls[8][2] == (1200.0, 800.0)   # :347-348
+    # HUD: black antialiased text at the reference's positions (game.py:351-428)
+    texts = {c[1][1].split(":")[0]: (c[2], c[1]) for c in fake.calls if c[0] == "blit"}
+    assert all(t[1][2] is True and t[1][3] == R.BLACK_RGB for t in texts.values())
+    want = {"pos": (20, 20), "v_air": (20, 40), "psi": (20, 60), "psi_dot": (20, 80), "a_lat": (20, 100), "a_lat_norm": (20, 120),
+            "Distance to goal": (20, 980), "Min. Separation": (20, 960), "Rel. angle to traffic": (20, 940),
+            "Closing Speed": (20, 920), "Closest approach": (20, 900), "Delta heading": (20, 880), "Plan deviation": (20, 860),
+            "Steps": (750, 980), "Episode": (750, 960), "Total reward": (1300, 980), "Step reward": (1300, 960),
+            "Step plan deviation reward": (1300, 940), "Step goal distance reward": (1300, 920),
+            "Step closest approach reward": (1300, 900), "Step heading reward": (1300, 880)}
+    assert {k: v[0] for k, v in texts.items()} == want
+    assert texts["psi_dot"][1][1] == "psi_dot: -10.0" and texts["a_lat_norm"][1][1] == "a_lat_norm: -0.102"   # a_lat / (v dt), a_lat / 20 g
+    assert texts["Rel. angle to traffic"][1][1] == "Rel. angle to traffic: 338.2"       # atan2(300 - 500, 900 - 400) mod 360
+    assert fake.calls[-1] == ("update",)                                                 # game.py:431
+    # closing the window: the QUIT event is seen by the next draw, which reports it
+    fake._events = [fake.QUIT]
+    assert win.draw(sc) is False and win.open is False
+    win.close()
+
+
+def test_adapter_quit_flag_follows_the_window(monkeypatch):
+    """ACAS2DEnv.render("human") -> PygameWindow.draw; a QUIT event sets env.game.quit, the flag the reference's
+    scripts poll (game.py:318-321, testing_main.py:71-72).  No GPU: the scene is handed in directly."""
+    import sys
+    fake = _RecordingPygame(events=[_RecordingPygame.QUIT])
+    monkeypatch.setitem(sys.modules, "pygame", fake)
+    monkeypatch.setattr(R.Scene, "from_env", classmethod(lambda cls, env, index=0: _scene()))
+    env = g.ACAS2DEnv.__new__(g.ACAS2DEnv)           # the adapter's render path only (constructing it needs a GPU)
+    env._window, env.game, env._vec = None, type("G", (), {"quit": False})(), type("V", (), {"close": lambda self: None})()
+    assert env.game.quit is False
+    env.render(mode="human")
+    assert env.game.quit is True and ("update",) in fake.calls
+    env.close()
+    assert ("display.quit",) not in fake.calls       # the window was already closed by the user
+    assert env._window is None
+
+
 @pytest.mark.gpu
 def test_adapter_renders_a_host_copy_of_its_state():
     """ACAS2DEnv.render("rgb_array") (environment.py:50-51 -> game.view()): the frame shows the env's own state, the

@@ -4,6 +4,7 @@
 # size and at 4 M envs (working set 1.5 GB >> 256 MB Infinity Cache: the calibration point where
 # HBM reads == algorithmic reads).  Run on the GPU box via gpurun; outputs under gpurun_out/<tag>/.
 tag=${1:-prof}
+export ACAS2D_BUILD_LABEL=${2:-unlabelled}      # goes into traffic.json: which build the counter passes were taken on
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 2000 --warmup 200 --no-extra --no-cpu-baseline > $O/bench_traced.json 2> $O/bench_traced.err
@@ -25,7 +26,7 @@ python3 $R/tools/summarize_profile.py $O
 # keep what is judged (gpurun merges at most 64 MiB back): the summary, the bench lines, the kernel-stats tables and
 # the step kernel's per-dispatch counter values; drop the raw trace / counter directories
 mkdir -p $O/keep
-cp $O/summary.json $O/bench_*.json $O/keep/ 2>/dev/null
+cp $O/summary.json $O/traffic.json $O/bench_*.json $O/keep/ 2>/dev/null
 for t in trace trace_f64_exact trace_f64_fast; do
   f=$(find $O/$t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/keep/${t}_kernel_stats.csv
 done

@@ -73,6 +73,24 @@ if cal[4194304]["FETCH_SIZE_KiB"]:
                                       "hbm_write_bytes_per_launch": wr_b,
                                       "hbm_bytes_per_launch": rd_b + wr_b,
                                       "algorithmic_bytes_per_launch": sum(alg_bytes(65536)) }
+# profiles/traffic.json (what bench.py prints as roofline.traffic): the read side under BOTH corrections -- the
+# factor fitted at 4 M envs (every input byte fetched from HBM exactly once there) and the guide's exact x 2 for
+# wide coalesced reads (MI355X_MICROARCH.md, HBM) -- for the headline size and for the 4 M-env run itself
+if cal[4194304]["FETCH_SIZE_KiB"] and cal[65536]["FETCH_SIZE_KiB"]:
+    recs = []
+    for E in (65536, 4194304):
+        f, w = cal[E]["FETCH_SIZE_KiB"] * 1024, cal[E]["WRITE_SIZE_KiB"] * 1024
+        recs.append({"envs": E, "traffic": N, "dtype": "f32", "hbm_bytes_per_launch": int(round(f * k_read + w)),
+                     "read_bytes": int(round(f * k_read)), "write_bytes": int(round(w)),
+                     "read_correction_fitted_at_4M_envs": k_read,
+                     "hbm_bytes_per_launch_guide_x2": int(round(2 * f + w)), "read_bytes_guide_x2": int(round(2 * f)),
+                     "FETCH_SIZE_KiB": cal[E]["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": cal[E]["WRITE_SIZE_KiB"],
+                     "algorithmic_bytes_per_launch": sum(alg_bytes(E)),
+                     "build": os.environ.get("ACAS2D_BUILD_LABEL", "unlabelled"),
+                     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --envs %d --launch "
+                               "eager`, per-dispatch mean over the step kernel; tools/profile_round.sh" % E})
+    out["traffic_json"] = recs
+    json.dump(recs, open(os.path.join(d, "traffic.json"), "w"), indent=1)
 # float64 builds: kernel-trace statistics and the SQ instruction mix per launch
 for m in ("exact", "fast"):
     ks = glob.glob(os.path.join(d, "trace_f64_" + m, "**", "*kernel_stats.csv"), recursive=True)
