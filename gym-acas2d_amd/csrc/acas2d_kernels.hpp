@@ -332,6 +332,36 @@ __device__ __forceinline__ T atan2_rev(T y, T x) {
     return p;
 }
 
+// float64 FAST: degrees(atan2(y, x) mod 2 pi) without the libm call (~120 double-rate instructions per lane and
+// step for the heading to the goal): one Newton-refined reciprocal, the quotient folded at pi/8 so that
+// |t| <= tan(pi/8), atan(t) = t + t u Q(u), u = t^2, Q of degree 9 (Chebyshev projection of atan(sqrt u)/sqrt u on
+// [0, 1.02 tan^2(pi/8)], evaluated offline in 40 digits: 8e-17 rad against atan over the interval), octant fix-ups
+// as in atan2_rev().  -0.0 never counts as negative (`atan2 % (2 pi)` maps -0.0 to +0.0); atan2(0, 0) = 0.
+__device__ __forceinline__ double atan2_deg_fast(double y, double x) {
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const bool fold = mn > 0.41421356237309503 * mx;                      // tan(pi / 8)
+    const double num = fold ? mn - mx : mn, den = fold ? mn + mx : mx;    // atan(m) = pi/4 + atan((m - 1) / (m + 1))
+    const double t = (den == 0.0) ? 0.0 : num * f_rcp(den);
+    const double u = t * t;
+    double q = 2.08423976756134700e-02;
+    q = __builtin_fma(q, u, -4.32403867209767631e-02);
+    q = __builtin_fma(q, u, 5.68001133607661315e-02);
+    q = __builtin_fma(q, u, -6.63863700978875593e-02);
+    q = __builtin_fma(q, u, 7.68976944121230882e-02);
+    q = __builtin_fma(q, u, -9.09076000844774024e-02);
+    q = __builtin_fma(q, u, 1.11111056188861551e-01);
+    q = __builtin_fma(q, u, -1.42857141672039500e-01);
+    q = __builtin_fma(q, u, 1.99999999986849059e-01);
+    q = __builtin_fma(q, u, -3.33333333333276305e-01);
+    double a = __builtin_fma(t * u, q, t);
+    if (fold) a += 0.78539816339744830962;
+    if (ay > ax) a = 1.57079632679489661923 - a;
+    if (x < 0.0) a = Const<double>::pi - a;
+    if (y < 0.0) a = Const<double>::two_pi - a;
+    return a * Const<double>::rad2deg;
+}
+
 // kinematics.py:82-83  builtin min(a, b) -> b only if b < a
 template <typename T>
 __device__ __forceinline__ T delta_heading(T psi, T phi) {
@@ -469,12 +499,17 @@ __device__ __forceinline__ int64_t remap_block(uint32_t trailing = 0u) {
     return b;
 }
 
-// ---- Philox4x32-10 counter-based reset RNG ---------------------------------------------------------
+// ---- Philox4x32-7 counter-based reset RNG -----------------------------------------------------------
+// Seven rounds: the fewest for which Random123 (Salmon et al., SC'11) publishes known-answer vectors and reports the
+// generator Crush-resistant (ten is its default, with a safety margin this use does not need: the words only place
+// aircraft).  A round is two dependent v_mad_u64_u32 on the wave that resets an env, i.e. on the launch's critical
+// path: 10 -> 7 rounds measured 5.43 -> 5.22 us per launch at 65 536 x 8 (tools/ab.sh, one box).  The CPU checker of the
+// test suite draws with the same seven rounds; both are pinned by the published vectors (tests/test_oracle_golden.py).
 struct U4 { uint32_t x, y, z, w; };
 #ifndef ACAS2D_PHILOX_ROUNDS
-#define ACAS2D_PHILOX_ROUNDS 10          // anything else: diagnostic builds only (the reset chain's latency knob)
+#define ACAS2D_PHILOX_ROUNDS 7           // anything else: diagnostic builds only (the reset chain's latency knob)
 #endif
-__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ U4 philox4x32(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < ACAS2D_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;   // v_mad_u64_u32
@@ -612,10 +647,10 @@ __device__ __forceinline__ OwnCtx<T> own_context(const Params<T>& p, const Own<T
         c.x1 = o.x + c.v1x; c.y1 = o.y + c.v1y;
         const T gdx = o.gx - o.x, gdy = o.gy - o.y;
         c.d_goal = f_sqrt(m_fma(gdy, gdy, gdx * gdx));
-        // materialised: evaluate() subtracts it from psi.  (float64: the degree-15 polynomial is a float32-grade
-        // 2.6e-8 rev; one libm atan2 per lane and step keeps the heading at 1e-13 degrees)
+        // materialised: evaluate() subtracts it from psi.  (float64: the degree-15 polynomial of atan2_rev() is
+        // float32-grade, 2.6e-8 rev; atan2_deg_fast() keeps the heading at 1e-14 degrees without the libm call)
         if constexpr (sizeof(T) == 4) c.h_goal = rounded(atan2_rev(gdy, gdx) * T(360));
-        else c.h_goal = relative_angle(o.x, o.y, o.gx, o.gy);
+        else c.h_goal = atan2_deg_fast(gdy, gdx);
         c.d_dev = gdy;            // d_goal * sin(atan2(gdy, gdx)) == gdy          (game.py:175-180)
         scalars(c);
     } else {
@@ -855,19 +890,12 @@ __device__ __forceinline__ T minimum_separation(const State<T>& s, const Own<T>&
 // of a wave's loads are in flight together) and write the moved block back; the generic walk
 // loads / stores aircraft by aircraft.
 // `after_own(c)` runs between the player side and the traffic side (the record rows' minimum separation).
-// `outcome_known(d_goal, collided)` (packed shapes) runs as soon as the step's outcome is decided -- the player has moved
-// (d_goal), every aircraft of the env has moved and its distance to the player is known (collided = OR over the
-// env's group), i.e. before the closest-approach / closing-speed arithmetic of the observation.
-struct NoHook {
-    template <typename X> __device__ __forceinline__ void operator()(const X&) const {}
-    template <typename X> __device__ __forceinline__ void operator()(X, int) const {}
-};
-template <typename T, int C, int G, bool PACKED, bool FAST, typename Hook = NoHook, typename Early = NoHook>
+struct NoHook { template <typename X> __device__ __forceinline__ void operator()(const X&) const {} };
+template <typename T, int C, int G, bool PACKED, bool FAST, typename Hook = NoHook>
 __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s, const Own<T>& o,
                                            int e, int j, int N, int32_t steps, bool move,
                                            Traffic<T, C>& tr, T* __restrict__ row, bool store_traffic = true,
-                                           TrigCache<T, C>* tc = nullptr, Hook after_own = Hook(),
-                                           Early outcome_known = Early()) {
+                                           TrigCache<T, C>* tc = nullptr, Hook after_own = Hook()) {
     const OwnCtx<T> c = own_context<T, FAST>(p, o);
     // Keep the traffic arithmetic below this line: the player side above needs only the scalars, which
     // were requested first, so it runs under s_waitcnt vmcnt(11..5) while the traffic vectors land.
@@ -945,8 +973,9 @@ __device__ __forceinline__ Seen<T> observe(const Params<T>& p, const State<T>& s
                 coll |= (dist[k] < p.collision_dist) ? 1 : 0;                    // game.py:185-189
             }
         }
+        // (the step's outcome is decided here: d_goal, the step counter and this OR -- before the closest-approach /
+        //  closing-speed arithmetic of the observation)
         r.collided = group_or<G>(coll);
-        outcome_known(c.d_goal, r.collided);
         if constexpr (PAIRS) {
 #pragma unroll
             for (int k = 0; k < C; k += 2) {
@@ -1005,7 +1034,7 @@ __device__ __forceinline__ void reset_entity(const R& rp, uint32_t k0, uint32_t 
                                              uint32_t g_hi, uint32_t episode, int ent, T& ox, T& oy, T& opsi,
                                              T& ov) {
 #pragma clang fp contract(off)
-    const U4 w = philox4x32_10(U4{g_lo, g_hi, episode, (uint32_t)ent}, k0, k1);
+    const U4 w = philox4x32(U4{g_lo, g_hi, episode, (uint32_t)ent}, k0, k1);
     if constexpr (sizeof(T) == 4) {
         const bool own = ent == 0, first = ent == 1;
         const float down = (float)(w.x >> 31), u_psi = u01f(w.z);
@@ -1271,123 +1300,6 @@ __device__ __forceinline__ unsigned long long wave_reset_slots(const Params<T>& 
     return taken;
 }
 
-// ---- the reset worker: a fifth wavefront per workgroup that draws the fresh episodes ---------------------------------
-// Per-step launches of the packed shapes with N + 1 <= 32 (acas2d_step_* with ACAS2D_AUTO_RESET).  A wave's
-// instruction stream issues at most one VALU instruction every four cycles however idle its SIMD is, and the reset
-// of a finished env is ~300 dependent instructions (Philox block, the drawn entity, the first observation) that the
-// finishing wave used to run AFTER its ordinary work, alone, while the launch waited for it (a wave with a finished
-// env lived 0.76 us longer than the others).  The outcome of a step is known long before its
-// observation is complete -- after the player and the traffic have moved and the distances are known (observe()'s
-// `outcome_known` hook) -- so the four stepping waves post their finishing envs to a mailbox in LDS at that point and
-// go on with the closest-approach / closing-speed / reward arithmetic, while the WORKER wave draws the new episodes
-// and their first observations into LDS slots, several envs side by side (ResetSlots: one entity per lane, the same
-// per-lane functions as the in-wave reset, hence the same bits).  At its end a stepping wave with finished envs
-// copies the fresh rows into its tile, hands the finished rows to term_obs and picks the new state up (commit).
-//
-// Protocol (words in LDS; a wave's DS operations execute in issue order):
-//   stepping wave:  takes request numbers r, r+1, ... for its finishing envs (one ds_add_rtn on n_req), writes
-//                   list[r] = (wave, env, episode counter), then adds 1 to `posted` -- every live stepping wave
-//                   does that last step, whatever it found;
-//   worker:         waits for posted == live stepping waves, reads n_req and serves the requests in batches of SLOTS
-//                   (request r -> slot r % SLOTS): before batch b > 0 it waits for consumed >= b * SLOTS (the slots
-//                   are free again), after each batch it sets served = b + 1; then it leaves;
-//   stepping wave:  at its end, for each of its finishing envs in turn: waits for served > r / SLOTS, commits slot
-//                   r % SLOTS, adds 1 to `consumed`.
-// No wait is circular: the worker waits for posts that are unconditional and for commits of batches it has already
-// served; a stepping wave waits for batches in increasing order.  Every wave of the grid reaches its end.
-struct WorkerBox {
-    uint32_t posted, n_req, served, consumed;
-    uint32_t pad[12];
-    uint32_t list[256][2];                                 // per request: wave << 16 | env in the wave, episode counter
-};
-constexpr int kWorkerBoxHead = 16;                         // words the worker clears
-template <typename T, int NS> struct WorkerSlot {          // one slot, in values of T: the state block, then the fresh row
-    static constexpr int W = 16 / (int)sizeof(T);
-    static constexpr int ROW = SlotLayout<T, NS>::STRIDE;
-    static constexpr int STRIDE = ROW + (5 + 3 * NS + W - 1) / W * W;
-};
-template <int C, int G, bool PACKED, bool AUTO_RESET, bool ROLLOUT> struct UsesWorker {
-#ifdef ACAS2D_NO_WORKER
-    static constexpr bool value = false;
-#else
-    static constexpr bool value = PACKED && AUTO_RESET && !ROLLOUT && ResetSlots<PACKED ? C * G : 1>::SLOTS >= 2 && kWavesPerBlock == 4;
-#endif
-};
-// mailbox words: volatile accesses in the LDS address space (ds_read_b32 / ds_write_b32 / ds_add, never flat)
-typedef __attribute__((address_space(3))) volatile uint32_t LdsWord;
-typedef __attribute__((address_space(3))) uint32_t LdsAtomicWord;
-__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return *(const LdsWord*)p; }
-__device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { *(LdsWord*)p = v; }
-__device__ __forceinline__ uint32_t lds_peek_s(const uint32_t* p) {            // wave-uniform address: the value as a scalar
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_peek(p));
-}
-__device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) {
-    return __hip_atomic_fetch_add((LdsAtomicWord*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// The worker wave.  `gid_block`: global index of the workgroup's first env, `n_main`: its live stepping waves.
-template <typename T, bool FAST, int NS, int G, typename R>
-__device__ __forceinline__ void reset_worker(const Params<T>& p, const R& rp, uint32_t k0, uint32_t k1, uint64_t gid_block,
-                                             int n_main, int lane, WorkerBox* box, T* __restrict__ slots) {
-    using RS = ResetSlots<NS>;
-    using WS = WorkerSlot<T, NS>;
-    constexpr int N = NS, EPW = 64 / G;
-    const int slot = lane / RS::STRIDE, ent = lane % RS::STRIDE;
-    // (what the generation reads from the kernel arguments, fetched before the wait instead of behind it)
-    asm volatile("" :: "s"(k0), "s"(k1), "s"(gid_block), "s"(rp.own_x0), "s"(rp.own_heading0), "s"(rp.t0_x), "s"(rp.tn_x_max),
-                 "s"(rp.airspeed), "s"(rp.d_goal0), "s"(rp.d_dev0));
-    while (lds_peek_s(&box->posted) != (uint32_t)n_main) __builtin_amdgcn_s_sleep(2);
-    const int n_req = (int)lds_peek_s(&box->n_req);        // final: every stepping wave has taken its numbers
-    for (int b = 0; b * RS::SLOTS < n_req; ++b) {
-        if (b > 0)                                          // the slots are free once the previous batch has been committed
-            while (lds_peek_s(&box->consumed) < (uint32_t)(b * RS::SLOTS)) __builtin_amdgcn_s_sleep(2);
-        // ---- the fresh episodes of the batch, one entity per lane: wave_reset_slots() without the term_obs part ----
-#ifndef ACAS2D_WORKER_PRIO
-#define ACAS2D_WORKER_PRIO 2
-#endif
-        __builtin_amdgcn_s_setprio(ACAS2D_WORKER_PRIO);    // the youngest wave of its SIMD would otherwise get the leftover issue slots
-        const int r = b * RS::SLOTS + slot;
-        const bool have = r < n_req;
-        const uint32_t who = have ? lds_peek(&box->list[r][0]) : 0u;
-        const uint32_t episode = have ? lds_peek(&box->list[r][1]) + 1u : 0u;
-        const uint64_t gid = gid_block + (uint64_t)((who >> 16) * EPW + (who & 0xffffu));
-        T* scr = slots + slot * WS::STRIDE;
-        T* frow = scr + WS::ROW;
-        T tx = T(0), ty = T(0), tpsi = T(0), tv = T(0);
-        const bool mine = have && ent <= N;
-        if (mine) {
-            reset_entity<T, R>(rp, k0, k1, (uint32_t)gid, (uint32_t)(gid >> 32), episode, ent, tx, ty, tpsi, tv);
-            if (ent == 0) scr[4 * N] = tpsi;
-            else { const int n = ent - 1; scr[n] = tx; scr[N + n] = ty; scr[2 * N + n] = tpsi; scr[3 * N + n] = tv; }
-        }
-        T psi_own;
-        if constexpr (sizeof(T) == 4 && RS::STRIDE == 16)
-            psi_own = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int((float)tpsi), 0x150, 0xf, 0xf, false));
-        else if constexpr (sizeof(T) == 4 && RS::STRIDE == 4)
-            psi_own = __int_as_float(quad_perm<0x00>(__float_as_int((float)tpsi)));
-        else if constexpr (sizeof(T) == 4 && RS::STRIDE == 2)
-            psi_own = __int_as_float(quad_perm<0xA0>(__float_as_int((float)tpsi)));
-        else {
-            wave_lds_fence();                              // the player's heading of every slot is in its state block
-            psi_own = have ? scr[4 * N] : T(0);
-        }
-        const Own<T> o{(T)rp.own_x0, (T)rp.own_y0, psi_own, (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-        const OwnCtx<T> c = own_context_fresh<T, FAST>(p, rp, o);
-        if (mine) {                                        // environment.py:44-48: the first observation (steps becomes 1)
-            if (ent >= 1) {
-                T d, dca, vc;
-                traffic_step<T, FAST>(p, c, false, tx, ty, tpsi, tv, d, dca, vc);
-                put_traffic_obs<T, FAST>(p, frow + 5 + 3 * (ent - 1), d, dca, vc);
-            } else {
-                put_own_obs<T, FAST>(p, frow, 1, o.psi, c);
-            }
-        }
-        wave_lds_fence();
-        __builtin_amdgcn_s_setprio(0);
-        if (lane == 0) lds_poke(&box->served, (uint32_t)(b + 1));     // (DS operations execute in order: the slots are written)
-    }
-}
-
 // Flush the wave's LDS tile (`count` values, the contiguous slice dst[0 .. count) of obs[E][D])
 // with lane-linear stores: 16 bytes per lane where the slice is 16-byte aligned, else one value.
 // Chunk c (16 bytes, or one value on the unaligned path) is always written by lane c % 64, so a
@@ -1550,7 +1462,7 @@ __device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&
 // a non-finite observation entry reaches the networks as 0 (the reference's NaN d_cpa in exact parallel flight).
 template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false,
           bool SAMPLE = false>
-__global__ __launch_bounds__((UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::value ? kBlock + 64 : kBlock)) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
+__global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int64_t n_envs, int N_arg,
                                                       int tile_elems, int n_steps, PolicyW pw) {
@@ -1574,28 +1486,9 @@ __global__ __launch_bounds__((UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::val
     const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
     const int wib = wave_in_block();
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    // Worker shapes (see reset_worker()): the workgroup has a fifth wave; the mailbox and the slots follow the four tiles.
-    constexpr bool WORKER = UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::value;
-    WorkerBox* const box = reinterpret_cast<WorkerBox*>(lds_raw + (size_t)kWavesPerBlock * tile_elems * sizeof(T));
-    T* const wslots = reinterpret_cast<T*>(lds_raw + (size_t)kWavesPerBlock * tile_elems * sizeof(T) + sizeof(WorkerBox));
-    if constexpr (WORKER) {
-        if (wib == kWavesPerBlock) {
-            if (lane < kWorkerBoxHead) lds_poke(reinterpret_cast<uint32_t*>(box) + lane, 0u);
-            __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the mailbox is clear ...
-            __builtin_amdgcn_s_barrier();                      // ... before any stepping wave posts to it
-#ifdef ACAS2D_WORKER_NOP
-            return;                                            // diagnostic (runs where nothing finishes only): the fifth wave's cost alone
-#endif
-            const int64_t e_block = remap_block() * kWavesPerBlock * EPW;
-            const int64_t left = n_envs - e_block;             // > 0: the workgroup exists for its first env
-            const int n_main = (int)(left >= (int64_t)kWavesPerBlock * EPW ? kWavesPerBlock : (left + EPW - 1) / EPW);
-            reset_worker<T, FAST, NS, G>(p_arg, rp, k0, k1, (uint64_t)(env_offset + e_block), n_main, lane, box, wslots);
-            return;
-        }
-    }
     const int64_t wave = remap_block() * kWavesPerBlock + wib;
     const int64_t e_wave = wave * EPW;             // first env of this wave (scalar)
-    if (e_wave >= n_envs) return;                  // whole wave idle (a finished wave no longer counts at the barrier)
+    if (e_wave >= n_envs) return;                  // whole wave idle
     const int D = 5 + 3 * N;
     const int n_rows = (int)((n_envs - e_wave) < EPW ? (n_envs - e_wave) : EPW);
     const bool active = el < n_rows;               // whole groups are active or not
@@ -1640,16 +1533,13 @@ __global__ __launch_bounds__((UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::val
         if constexpr (!POLICY) action_next = io0.actions[el_l];
         if constexpr (PACKED) tr = load_traffic<T, C>(s, el_l * N + j * C);
     }
-    // The worker has cleared the mailbox before it joins this barrier.  (inline asm: behind the intrinsic hipcc puts
-    // s_waitcnt vmcnt(0) lgkmcnt(0) in front of every barrier on this target -- the loads above would have to land here)
-    if constexpr (WORKER) asm volatile("s_barrier" ::: "memory");
 
     // Launch constants into VGPRs only now, AFTER the loads are in flight: pinned() is ~25 v_movs
     // behind a kernarg s_load round trip, which used to sit in front of the first global load.
     // (not for the policy rollout: its MLP needs the 25 registers more than it minds re-fetching
     // launch constants, and has to stay under 256 VGPRs to keep two waves per SIMD)
     const Params<T> p = POLICY ? p_arg : pinned(p_arg);
-    if constexpr (AUTO_RESET && !ROLLOUT && !WORKER) {
+    if constexpr (AUTO_RESET && !ROLLOUT) {
         // ... and what the reset of a finished env reads, so that its wave does not start the reset
         // with a scalar-load round trip (the kernel ends with that wave)
         asm volatile("" :: "s"(rp.own_x0), "s"(rp.own_y0), "s"(rp.own_v), "s"(rp.own_heading0), "s"(rp.own_heading_jitter),
@@ -1675,8 +1565,6 @@ __global__ __launch_bounds__((UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::val
                            io0.ep_steps ? io0.ep_steps + te : nullptr};
         const bool last = !ROLLOUT || t == T_steps - 1;
         uint8_t oc = 0;
-        unsigned long long dm_posted = 0;                      // worker shapes: what outcome_known() posted ...
-        uint32_t req_no = 0;                                   // ... and the request number of the lane's env
         T action = action_next;
         if constexpr (POLICY) {
             constexpr int DP = 5 + 3 * NS;                // compile-time obs width (packed shapes)
@@ -1699,7 +1587,7 @@ __global__ __launch_bounds__((UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::val
                 const float log_std = ((const float ACAS2D_AS4*)pw_t.log_std)[0];
                 // eps ~ N(0, 1): one Philox block per (global env, noise step + t), Box-Muller on two 24-bit uniforms
                 const uint64_t gid = (uint64_t)(env_offset + e_wave + el);
-                const U4 w = philox4x32_10(U4{(uint32_t)gid, (uint32_t)(gid >> 32), pw.noise_step + (uint32_t)t, 0x6e6f6973u},
+                const U4 w = philox4x32(U4{(uint32_t)gid, (uint32_t)(gid >> 32), pw.noise_step + (uint32_t)t, 0x6e6f6973u},
                                            pw.nk0, pw.nk1);
                 const float u1 = u01f(w.x), u2 = u01f(w.y);
                 const float eps = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) *    // -2 ln u1
@@ -1747,24 +1635,8 @@ __global__ __launch_bounds__((UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::val
             auto before_traffic = [&](const OwnCtx<T>&) {
                 if constexpr (!AUTO_RESET) { if (s.trace) d_sep = minimum_separation<T, C, G, PACKED>(s, o, tr, el, j, N); }
             };
-            // Worker shapes: the step's outcome is decided here -- post the finishing envs, the worker draws their next
-            // episodes while this wave completes the observation and the reward (see reset_worker()).
-            auto outcome_known = [&](T d_goal, int collided) {
-                if constexpr (WORKER) {
-                    const bool fin_e = active && ((steps > p.max_steps) || collided != 0 || d_goal < p.goal_radius) && j == 0;
-                    dm_posted = __ballot(fin_e);
-                    if (dm_posted != 0ull) {                          // (wave-uniform; rare)
-                        uint32_t base = 0u;
-                        if (lane == 0) base = lds_add(&box->n_req, (uint32_t)__popcll(dm_posted));
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        req_no = base + (uint32_t)__popcll(dm_posted & ((1ull << lane) - 1ull));
-                        if (fin_e) { lds_poke(&box->list[req_no][0], ((uint32_t)wib << 16) | (uint32_t)el); lds_poke(&box->list[req_no][1], episode); }
-                    }
-                    if (lane == 0) (void)lds_add(&box->posted, 1u);
-                }
-            };
             Seen<T> r = observe<T, C, G, PACKED, FAST>(p, s, o, el, j, N, steps, !frozen, tr, row, last && active,
-                                                       ROLLOUT ? &trig : nullptr, before_traffic, outcome_known);
+                                                       ROLLOUT ? &trig : nullptr, before_traffic);
 
             // game.py:249-292 evaluate()
             T rw = step_reward_5<T, FAST>(p, r.v_closing0, o.psi, r.h_goal, r.d_cpa0, r.d_goal, r.d_dev);
@@ -1809,52 +1681,7 @@ __global__ __launch_bounds__((UsesWorker<C, G, PACKED, AUTO_RESET, ROLLOUT>::val
             bool fresh = false, same_consts = false;
             unsigned long long dm = __ballot(oc != 0 && j == 0);
             constexpr bool SLOTTED = ResetSlots<NS>::SLOTS >= 2;      // N + 1 <= 32: several envs per pass
-            if constexpr (WORKER) {
-                // ---- the worker wave drew the new episodes (reset_worker()): commit them, one finished env after the other
-                //      (dm == dm_posted: the same steps / distances / d_goal decide both) ----
-                using RS = ResetSlots<NS>;
-                using WS = WorkerSlot<T, NS>;
-                using SL = SlotLayout<T, NS>;
-                while (dm) {
-                    const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)dm) - 1);   // wave-uniform
-                    dm &= dm - 1ull;
-                    const uint32_t r = (uint32_t)lane_value((int)req_no, src);
-                    while (lds_peek_s(&box->served) <= r / RS::SLOTS) __builtin_amdgcn_s_sleep(1);
-                    const int e_s = src / G;
-                    T* row_s = tile + e_s * D;
-                    const T* scr = wslots + (r % RS::SLOTS) * WS::STRIDE;
-                    const T* frow = scr + WS::ROW;
-                    wave_lds_fence();                     // every row of the tile is complete
-                    // the finished row to term_obs, the fresh row into the tile
-                    for (int i = lane; i < D; i += 64) {
-                        const T old = row_s[i], fresh_v = frow[i];
-                        if (io.term_obs) (io.term_obs + e_s * D)[i] = old;
-                        row_s[i] = fresh_v;
-                    }
-                    if (el == e_s) {                      // the owner group goes on with the new episode
-                        if (j == 0) {
-                            if (io.ep_return) io.ep_return[el] = total;
-                            if (io.ep_steps) io.ep_steps[el] = steps;
-                        }
-                        using V = Vec<T, C>;              // the slot's blocks are aligned like the live traffic block
-                        tr.x = *reinterpret_cast<const V*>(scr + j * C);
-                        tr.y = *reinterpret_cast<const V*>(scr + N + j * C);
-                        tr.psi = *reinterpret_cast<const V*>(scr + 2 * N + j * C);
-                        tr.v = *reinterpret_cast<const V*>(scr + 3 * N + j * C);
-                        same_consts = o.v == (T)rp.own_v && o.gx == (T)rp.goal_x && o.gy == (T)rp.goal_y;
-                        o = Own<T>{(T)rp.own_x0, (T)rp.own_y0, scr[SL::OWN_PSI], (T)rp.own_v, T(0), (T)rp.goal_x, (T)rp.goal_y};
-                        steps = 1;                                            // environment.py:47
-                        total = T(0);
-                        episode += 1u;
-                        fresh = true;
-                        const int i0 = el * N + j * C;
-                        put_trf<T, C>(s, s.trf_x, i0, tr.x); put_trf<T, C>(s, s.trf_y, i0, tr.y);
-                        *reinterpret_cast<V*>(s.trf_psi + i0) = tr.psi; *reinterpret_cast<V*>(s.trf_v + i0) = tr.v;
-                    }
-                    wave_lds_fence();                     // the slot has been read ...
-                    if (lane == 0) (void)lds_add(&box->consumed, 1u);     // ... (DS operations execute in order) and may be reused
-                }
-            } else if constexpr (SLOTTED) {
+            if constexpr (SLOTTED) {
                 using SL = SlotLayout<T, NS>;
                 while (dm) {
                     wave_lds_fence();                     // every row of the tile is complete

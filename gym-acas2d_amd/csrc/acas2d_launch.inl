@@ -103,18 +103,8 @@ static int check_launch(const char* what) {
 // workgroup, one LDS observation tile per wavefront.
 struct Geometry { unsigned grid, block; int tile_elems; size_t lds_bytes; };
 
-// The per-step auto-reset launch of a packed shape with N + 1 <= 32 runs with a fifth wavefront per workgroup, the
-// reset worker (acas2d_kernels.hpp, reset_worker(); UsesWorker<> there is this predicate at compile time).
-static bool worker_shape(const Shape& sh, int n_traffic) {
-#ifdef ACAS2D_NO_WORKER
-    return false;
-#else
-    return sh.packed && n_traffic + 1 <= 32 && kWavesPerBlock == 4;
-#endif
-}
-
 template <typename T>
-static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g, bool worker = false) {
+static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g) {
     const int64_t epw = 64 / sh.G, envs_per_block = epw * kWavesPerBlock;
     const int64_t blocks = (n_envs + envs_per_block - 1) / envs_per_block;
     if (blocks > 0x7fffffffLL) { set_error("n_envs = %lld exceeds the grid limit", (long long)n_envs); return ACAS2D_EINVAL; }
@@ -122,24 +112,20 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
     // per wave: the observation tile, then the reset slots (SlotLayout<T, N> in the kernels; packed shapes with
     // N + 1 <= 32) or one 4N+1-value hand-off scratch (the other packed shapes), everything 16-byte aligned
     const int64_t tile = (epw * (5 + 3 * (int64_t)n_traffic) + 3) / 4 * 4;
-    int64_t scratch = 0, shared = 0;
+    int64_t scratch = 0;
     if (sh.packed && n_traffic + 1 <= 32) {
         int stride = 2; while (stride < n_traffic + 1) stride *= 2;
-        const int64_t state = (4 * (int64_t)n_traffic + 1 + W - 1) / W * W;
-        if (worker)      // the workgroup's mailbox and slots (WorkerBox / WorkerSlot) behind the four tiles, no per-wave scratch
-            shared = (int64_t)sizeof(WorkerBox) + (64 / stride) * (state + (5 + 3 * (int64_t)n_traffic + W - 1) / W * W) * (int64_t)sizeof(T);
-        else
-            scratch = (64 / stride) * state;
+        scratch = (64 / stride) * ((4 * (int64_t)n_traffic + 1 + W - 1) / W * W);
     } else if (sh.packed) {
         scratch = 4 * (int64_t)n_traffic + 1;
     }
     const int64_t elems = ((tile + scratch + 3) / 4) * 4;
-    const int64_t bytes = elems * kWavesPerBlock * (int64_t)sizeof(T) + shared;
+    const int64_t bytes = elems * kWavesPerBlock * (int64_t)sizeof(T);
     if (bytes > 64 * 1024) {
         set_error("n_traffic = %d needs a %lld-byte LDS observation tile per workgroup (limit 65536)", n_traffic, (long long)bytes);
         return ACAS2D_EINVAL;
     }
-    g->grid = (unsigned)blocks; g->block = (unsigned)(kBlock + (worker ? 64 : 0)); g->tile_elems = (int)elems; g->lds_bytes = (size_t)bytes;
+    g->grid = (unsigned)blocks; g->block = (unsigned)kBlock; g->tile_elems = (int)elems; g->lds_bytes = (size_t)bytes;
     return ACAS2D_OK;
 }
 
@@ -225,7 +211,7 @@ static int launch_step_impl(const Acas2dConfig* cfg, const Acas2dState* st, cons
     if (int rc = resolve_shape<T>(n_traffic, &sh)) return rc;
     const bool ar = (flags & ACAS2D_AUTO_RESET) != 0;
     Geometry g;
-    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g, ar && worker_shape(sh, n_traffic))) return rc;
+    if (int rc = geometry_for<T>(sh, n_envs, n_traffic, &g)) return rc;
     const Params<T> p = make_params<T>(*cfg);
     const ResetParamsT<T> rp = make_reset_params<T>(*cfg);
     State<T> s = make_state<T>(*st);

@@ -95,11 +95,13 @@ class ACAS2DVecEnv:
     record_trace   (auto_reset=False only) keep `trace` [E, 16]: the per-step record row behind
                    testing_main.py:114-138's CSV columns (include/acas2d.h, Acas2dState.trace;
                    TRACE_COLUMNS below), rewritten by every reset*() / set_state(observe=True) / step()
-    double_buffer  (default: auto_reset) keep TWO generations of the arrays a step rewrites for every env
-                   (own_x, own_y, own_psi, steps, total_reward, trf_x, trf_y): step() reads the live one and
-                   writes the other, then they swap -- bit-identical to stepping in place and 0.4 us per launch
-                   faster at 65 536 x 8 (stores that do not hit lines the launch loaded leave the L2s during the
-                   kernel instead of in the write-back after it).  `env.own_x` etc. always
+    double_buffer  keep TWO generations of the arrays a step rewrites for every env (own_x, own_y, own_psi, steps,
+                   total_reward, trf_x, trf_y): step() reads the live one and writes the other, then they swap --
+                   bit-identical to stepping in place.  Default (None): on where it was measured to pay -- auto_reset
+                   envs whose step launch is a single generation of wavefronts (at most two per SIMD: 65 536 x 8
+                   float32 -0.4 us per launch, stores that do not hit lines the launch loaded leave the L2s during
+                   the kernel instead of in the write-back after it) -- and off for larger launches, where it was
+                   measured slower (131 072 x 8: 9.0 against 7.3 us).  `env.own_x` etc. always
                    name the LIVE generation: fetch them again after a step() instead of keeping the tensor.
                    hipGraph users: a graph captures the generation it was captured at -- call
                    `align_generation(g)` (g = `generation` at capture time) before each replay and capture an
@@ -135,7 +137,10 @@ class ACAS2DVecEnv:
 
         E, N, D, dev = self.num_envs, self.n_traffic, self.obs_dim, self.device
         z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=dev)  # noqa: E731
-        self.double_buffer = self.auto_reset if double_buffer is None else bool(double_buffer)
+        if double_buffer is None:           # measured policy: one generation of waves (<= 2 per SIMD on the 1 024 SIMDs)
+            geo = native.launch_geometry(self.num_envs, self.n_traffic, 4 if dtype == torch.float32 else 8)
+            double_buffer = self.auto_reset and self.num_envs * geo["lanes_per_env"] <= 2 * 1024 * 64
+        self.double_buffer = bool(double_buffer)
         if self.double_buffer and not self.auto_reset:
             raise ValueError("double_buffer needs auto_reset=True (the latching step leaves frozen traffic unwritten)")
         G = 2 if self.double_buffer else 1

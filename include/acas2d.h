@@ -145,7 +145,7 @@ const char *acas2d_last_error(void);  /* thread-local; valid until the next fail
  * envs: game.action -> game.observe -> game.evaluate -> game.is_done, one kernel launch.
  *   flags & ACAS2D_AUTO_RESET: finished envs store term_obs/ep_return/ep_steps, bump episode[e],
  *     are re-initialised with the distribution of game.py:80-116 from the counter-based RNG
- *     Philox4x32-10(key = seed, counter = (env_offset + e, episode[e], entity)) and return the
+ *     Philox4x32-7(key = seed, counter = (env_offset + e, episode[e], entity)) and return the
  *     new episode's first observation in obs (SB3 DummyVecEnv.step_wait semantics).
  *   otherwise: status[e] latches the outcome; stepping a finished env keeps moving the player
  *     but freezes its traffic (game.py:243-245).
@@ -227,7 +227,7 @@ int acas2d_rollout_policy_f64(const Acas2dConfig *cfg, const Acas2dState *state,
  *   v1t .. vb3                        the value net, same layout as the actor (mlp_extractor.value_net.{0,2}, value_net)
  *   log_std                           float[1]
  *   values, logp                      T[n_steps][E] outputs: V(obs_t), log N(action_t; mean_t, exp(log_std))
- *   noise_seed, noise_step            eps ~ N(0, 1) comes from Philox4x32-10(key = noise_seed, counter = (env_offset + e,
+ *   noise_seed, noise_step            eps ~ N(0, 1) comes from Philox4x32-7(key = noise_seed, counter = (env_offset + e,
  *                                     noise_step + t, tag)) by Box-Muller: the stream depends on the global env index and
  *                                     the step number only (pass the number of steps collected so far)
  * A non-finite observation entry (the reference's NaN d_cpa in exact parallel flight, kinematics.py:48) reaches the

@@ -159,10 +159,10 @@ static double step_reward_5(const Acas2dOracleConfig *c, double v_closing, doubl
 
 /* ---- counter-based reset RNG (build-defined; the reference uses global MT19937) ---------- */
 
-void acas2d_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+void acas2d_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4])
 {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -186,7 +186,7 @@ static void reset_env(const Acas2dOracleConfig *c, const Acas2dOracleState *st, 
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), st->episode[e], 0u}, w[4];
 
-    acas2d_oracle_philox4x32_10(ctr, key, w);
+    acas2d_oracle_philox4x32(ctr, key, ACAS2D_ORACLE_RESET_PHILOX_ROUNDS, w);
     st->goal_x[e] = c->goal_x;                                            /* game.py:80-81 */
     st->goal_y[e] = c->goal_y;
     st->own_x[e] = c->own_x0;                                             /* game.py:85-87 */
@@ -197,7 +197,7 @@ static void reset_env(const Acas2dOracleConfig *c, const Acas2dOracleState *st, 
                             360.0);                                       /* game.py:91-92 */
     for (int32_t n = 0; n < N; ++n) {
         ctr[3] = 1u + (uint32_t)n;
-        acas2d_oracle_philox4x32_10(ctr, key, w);
+        acas2d_oracle_philox4x32(ctr, key, ACAS2D_ORACLE_RESET_PHILOX_ROUNDS, w);
         double x, y, psi;
         double v = uniform(c->speed_factor_min, c->speed_factor_max, u01(w[3])) * c->airspeed;
         if (n == 0) {                                                     /* game.py:97-106 */

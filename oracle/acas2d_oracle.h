@@ -66,9 +66,11 @@ typedef struct Acas2dOracleState {
     uint32_t *episode;
 } Acas2dOracleState;
 
-/* Philox4x32-10 (Salmon et al., SC'11) -- the counter-based RNG of the build-defined device
- * reset.  Not part of the reference (which draws from Python's global MT19937, game.py:41-114). */
-void acas2d_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* Philox4x32-R (Salmon et al., SC'11; Random123) -- the counter-based RNG of the build-defined device
+ * reset: the engine and this oracle draw with R = 7 rounds, the fewest Random123 publishes known-answer
+ * vectors for (tests/test_oracle_golden.py checks R = 7 and R = 10 against them). */
+#define ACAS2D_ORACLE_RESET_PHILOX_ROUNDS 7
+void acas2d_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
 
 /* Reset envs [0, n_envs) with the distribution of game.py:80-116 using Philox keyed on
  * (seed, env_offset + e, episode[e]); sets steps = 0, total_reward = 0, status = 0.  If `mask`

@@ -98,8 +98,8 @@ def lib():
         _lib.acas2d_oracle_set_threads.restype = C.c_int
         _lib.acas2d_oracle_set_threads.argtypes = [C.c_int]
         _lib.acas2d_oracle_set_threads(1)                 # the scalar port unless a caller asks otherwise
-        _lib.acas2d_oracle_philox4x32_10.restype = None
-        _lib.acas2d_oracle_philox4x32_10.argtypes = [C.c_void_p] * 3
+        _lib.acas2d_oracle_philox4x32.restype = None
+        _lib.acas2d_oracle_philox4x32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib.acas2d_oracle_reset.restype = None
         _lib.acas2d_oracle_reset.argtypes = [C.POINTER(OracleConfig), C.POINTER(OracleState), C.c_void_p,
                                              C.c_uint64, C.c_int64, C.c_int64, C.c_int32]
@@ -120,11 +120,14 @@ def set_threads(n):
     return int(lib().acas2d_oracle_set_threads(int(n)))
 
 
-def philox4x32_10(ctr, key):
-    ctr = np.ascontiguousarray(ctr, np.uint32)
-    key = np.ascontiguousarray(key, np.uint32)
+RESET_PHILOX_ROUNDS = 7          # acas2d_oracle.h: ACAS2D_ORACLE_RESET_PHILOX_ROUNDS (the engine's reset RNG)
+
+
+def philox4x32(ctr, key, rounds=RESET_PHILOX_ROUNDS):
+    ctr = np.asarray(ctr, np.uint32)
+    key = np.asarray(key, np.uint32)
     out = np.zeros(4, np.uint32)
-    lib().acas2d_oracle_philox4x32_10(ctr.ctypes.data, key.ctypes.data, out.ctypes.data)
+    lib().acas2d_oracle_philox4x32(ctr.ctypes.data, key.ctypes.data, int(rounds), out.ctypes.data)
     return out
 
 

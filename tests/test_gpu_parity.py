@@ -44,6 +44,15 @@ def math(request):
     return request.param
 
 
+def bits_equal(x, y):
+    """torch.equal on the BIT patterns: the engine reproduces the reference's NaN d_cpa in exact parallel flight
+    (kinematics.py:48), which float32 headings hit about once per 4e6 env-steps at N = 8 -- and NaN != NaN."""
+    if x.is_floating_point():
+        bits = torch.int32 if x.dtype == torch.float32 else torch.int64
+        return x.shape == y.shape and torch.equal(x.contiguous().view(bits), y.contiguous().view(bits))
+    return torch.equal(x, y)
+
+
 class GpuEngine:
     """The HIP path behind the OracleEnvs interface (numpy float64 views), see helpers.py."""
 
@@ -604,7 +613,7 @@ def test_f32_reset_names_the_same_episodes(g, O):
             twin._launch_reset(fresh.to(torch.uint8), do_init=1)
             for name in ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi", "trf_v"):
                 assert torch.equal(getattr(twin, name)[fresh], getattr(env.v, name)[fresh]), name
-            assert torch.equal(twin.outputs["obs"][fresh], env.v.outputs["obs"][fresh])
+            assert bits_equal(twin.outputs["obs"][fresh], env.v.outputs["obs"][fresh])
     assert checked > 50
 
 
@@ -633,26 +642,26 @@ def test_rollout_equals_sequential_steps(g, dtype_name, N, E, T):
     dones = 0
     for t in range(T):
         obs, rew, done, infos = b.step(actions[t])
-        assert torch.equal(out["obs"][t], obs), t
-        assert torch.equal(out["reward"][t], rew) and torch.equal(out["done"][t], done)
-        assert torch.equal(out["outcome"][t], infos.outcome)
+        assert bits_equal(out["obs"][t], obs), t
+        assert bits_equal(out["reward"][t], rew) and bits_equal(out["done"][t], done)
+        assert bits_equal(out["outcome"][t], infos.outcome)
         d = done
         if bool(d.any()):
             dones += int(d.sum())
-            assert torch.equal(out["episode_return"][t][d], infos.episode_return[d])
-            assert torch.equal(out["episode_steps"][t][d], infos.episode_steps[d])
-            assert torch.equal(out["terminal_observation"][t][d], infos.terminal_observation[d])
+            assert bits_equal(out["episode_return"][t][d], infos.episode_return[d])
+            assert bits_equal(out["episode_steps"][t][d], infos.episode_steps[d])
+            assert bits_equal(out["terminal_observation"][t][d], infos.terminal_observation[d])
     assert dones > 0
     for name in ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi", "trf_v",
                  "steps", "total_reward", "episode"):
-        assert torch.equal(getattr(a, name), getattr(b, name)), name
-    assert torch.equal(a.outputs["obs"], b.outputs["obs"])          # the latest observation, either way
+        assert bits_equal(getattr(a, name), getattr(b, name)), name
+    assert bits_equal(a.outputs["obs"], b.outputs["obs"])          # the latest observation, either way
     # and a second rollout continues from the state the first one left, reusing the buffers
     actions2 = torch.rand(T, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
     out = a.rollout(actions2, out=out)
     for t in range(T):
         obs, rew, done, _ = b.step(actions2[t])
-        assert torch.equal(out["obs"][t], obs) and torch.equal(out["done"][t], done)
+        assert bits_equal(out["obs"][t], obs) and bits_equal(out["done"][t], done)
     with pytest.raises(RuntimeError, match="packed work shape"):
         g.ACAS2DVecEnv(16, 5, device=dev, dtype=dtype).rollout(torch.zeros(2, 16, device=dev, dtype=dtype))
 
@@ -677,7 +686,7 @@ def test_rollout_wraps_and_stores_injected_headings_like_steps(g, dtype_name):
     out = a.rollout(actions)
     for t in range(T):
         obs, rew, done, _ = b.step(actions[t])
-        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew), t
+        assert bits_equal(out["obs"][t], obs) and bits_equal(out["reward"][t], rew), t
     for name in ("own_psi", "trf_psi", "trf_x", "trf_y", "own_x", "own_y", "steps", "episode"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert float(a.trf_psi.max()) < 360.0 and float(a.own_psi.max()) < 360.0
@@ -714,7 +723,7 @@ def test_results_do_not_depend_on_the_work_shape(g, dtype_name, N, shapes):
                 ref = got
             else:
                 for k, (a, b) in enumerate(zip(ref, got)):
-                    assert torch.equal(a, b), (sh, k)
+                    assert bits_equal(a, b), (sh, k)
     finally:
         os.environ.pop("ACAS2D_SHAPE", None)
 
@@ -734,7 +743,7 @@ def test_double_buffered_step_equals_in_place(g, dtype_name, N, E, T):
 
     gen = torch.Generator(device="cuda:0").manual_seed(11)
     actions = torch.rand(T, E, generator=gen, device="cuda:0", dtype=dtype) * 2 - 1
-    a = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=21, env_offset=3, config=cfg)
+    a = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=21, env_offset=3, config=cfg, double_buffer=True)
     b = g.ACAS2DVecEnv(E, N, device="cuda:0", dtype=dtype, seed=21, env_offset=3, config=cfg, double_buffer=False)
     assert a.double_buffer and not b.double_buffer and a._gen["own_x"].shape[0] == 2 and b._gen["own_x"].shape[0] == 1
     assert same(a.reset(), b.reset())
@@ -771,8 +780,8 @@ def test_double_buffered_steps_in_a_replayed_graph(g):
     E, N, CH = 2048, 8, 6
     gen = torch.Generator(device="cuda:0").manual_seed(2)
     actions = torch.rand(CH, E, generator=gen, device="cuda:0") * 2 - 1
-    a = g.ACAS2DVecEnv(E, N, device="cuda:0", seed=4)
-    b = g.ACAS2DVecEnv(E, N, device="cuda:0", seed=4)
+    a = g.ACAS2DVecEnv(E, N, device="cuda:0", seed=4, double_buffer=True)
+    b = g.ACAS2DVecEnv(E, N, device="cuda:0", seed=4, double_buffer=True)
     a.reset(); b.reset()
     for t in range(3):                      # warm-up before the capture (an odd number: generation 1 is live)
         a.step_from(actions[t]); b.step_from(actions[t])
@@ -794,11 +803,15 @@ def test_double_buffered_steps_in_a_replayed_graph(g):
         for t in range(CH):
             b.step_from(actions[t])
         torch.cuda.synchronize()
-        assert torch.equal(a.outputs["obs"], b.outputs["obs"]) and torch.equal(a.outputs["reward"], b.outputs["reward"])
+        assert bits_equal(a.outputs["obs"], b.outputs["obs"]) and bits_equal(a.outputs["reward"], b.outputs["reward"])
         for name in ("own_x", "own_psi", "trf_y", "steps", "total_reward", "episode"):
             assert torch.equal(getattr(a, name), getattr(b, name)), (rep, name)
     with pytest.raises(RuntimeError):
         g.ACAS2DVecEnv(64, 1, device="cuda:0", double_buffer=False).align_generation(1)
+    # the default is the measured policy: on for launches of one generation of wavefronts (the headline size), off beyond
+    assert g.ACAS2DVecEnv(65536, 8, device="cuda:0").double_buffer and g.ACAS2DVecEnv(65536, 8, device="cuda:0", dtype=torch.float64).double_buffer
+    assert not g.ACAS2DVecEnv(131072, 8, device="cuda:0").double_buffer and not g.ACAS2DVecEnv(16384, 64, device="cuda:0").double_buffer
+    assert not g.ACAS2DVecEnv(64, 1, device="cuda:0", auto_reset=False).double_buffer
     with pytest.raises(ValueError):
         g.ACAS2DVecEnv(64, 1, device="cuda:0", auto_reset=False, double_buffer=True)
 
@@ -879,14 +892,14 @@ def test_fused_policy_rollout_equals_policy_then_step(g, N, E, T):
         worst_a = max(worst_a, float((out["actions"][t] - act).abs().max()))
         same &= out["actions"][t] == act
         obs, rew, done, infos = b.step(out["actions"][t])          # feed the fused run's own actions
-        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew), t
+        assert bits_equal(out["obs"][t], obs) and bits_equal(out["reward"][t], rew), t
         assert torch.equal(out["done"][t], done) and torch.equal(out["outcome"][t], infos.outcome), t
         obs = obs.clone()
     assert worst_a < 1e-5, worst_a
     assert float(out["actions"].abs().max()) > 0.2 and int(out["done"].sum()) > 0
     for name in ("own_x", "own_y", "own_psi", "trf_x", "trf_y", "steps", "total_reward", "episode"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
-    assert torch.equal(a.outputs["obs"], b.outputs["obs"])
+    assert bits_equal(a.outputs["obs"], b.outputs["obs"])
     with pytest.raises(RuntimeError, match="thread-per-env"):
         g.ACAS2DVecEnv(64, 16, device=dev).rollout_policy(g.ActorCritic(53).to(dev), 2)
 
@@ -938,7 +951,7 @@ def test_full_size_f64_vs_oracle(g, O, E, N, T):
     assert np.array_equal(env.steps, ref.steps) and np.array_equal(env.episode, ref.episode)
 
 
-@pytest.mark.parametrize("E,N,T", ((4096, 3, 12), (65536, 8, 5), (65536, 64, 3)))
+@pytest.mark.parametrize("E,N,T", ((4096, 3, 24), (65536, 8, 5), (65536, 64, 3)))
 def test_full_size_f32_vs_f64_oracle(g, O, E, N, T):
     """The headline dtype at the three single-GPU BASELINE sizes against the float64 oracle: T steps
     WITH auto-reset, each from the oracle trajectory's state rounded to float32 (so that both sides start every step
@@ -1024,7 +1037,7 @@ def test_full_size_f32_vs_f64_oracle(g, O, E, N, T):
           "(%d env-steps inside it); max |obs| %.2e, d_cpa %.2e, reward %.2e, terminal obs %.2e, first obs of a fresh "
           "episode %.2e" % (E, N, T, tot["steps"], tot["finished"], tot["mask_mismatch"], tot["in_band"], tot["e_obs"],
                             tot["e_cpa"], tot["e_rew"], tot["e_term"], tot["e_fresh_obs"]))
-    assert tot["finished"] > (50 if N == 3 else 300)
+    assert tot["finished"] > (40 if N == 3 else 300)
 
 
 @pytest.mark.parametrize("dtype_name", ("float32", "float64"))
@@ -1049,8 +1062,8 @@ def test_full_size_properties(g, dtype_name):
         o2, r2, d2, _ = again.step(a)
         oa, ra, da, _ = a_sh.step(a[:40000].contiguous())
         ob, rb, db, _ = b_sh.step(a[40000:].contiguous())
-        assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(done, d2)
-        assert torch.equal(obs, torch.cat([oa, ob])) and torch.equal(rew, torch.cat([ra, rb]))
+        assert bits_equal(obs, o2) and bits_equal(rew, r2) and torch.equal(done, d2)
+        assert bits_equal(obs, torch.cat([oa, ob])) and bits_equal(rew, torch.cat([ra, rb]))
         assert torch.equal(done, torch.cat([da, db]))
         steps = full.steps
         # steps advance by one, or restart at 1 exactly where done

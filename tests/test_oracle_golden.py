@@ -3,7 +3,7 @@
   * the reference's own CSV  models/logs/baseline_ACAS2D_PPO_11_100.csv  (digest fixture),
   * known answers printed in the reference's notebooks/rewards.ipynb,
   * vectors captured from the unmodified reference (oracle/refharness/capture_golden.py),
-  * Random123's published Philox4x32-10 known-answer vectors (the build-defined reset RNG).
+  * Random123's published Philox4x32 known-answer vectors, 7 rounds (the build-defined reset RNG) and 10.
 """
 import numpy as np
 import pytest
@@ -19,13 +19,19 @@ def O(oracle_mod):
 
 
 def test_philox_known_answers(O):
-    # Random123 kat_vectors, philox4x32 10 rounds
-    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
-           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
-           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
-            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
-    for ctr, key, want in kat:
-        assert list(O.philox4x32_10(ctr, key)) == want
+    # Random123 kat_vectors: philox4x32 with 7 rounds (what the reset RNG of the engine and of this oracle runs) and
+    # with 10 (the library's default) -- counter, key, expected words
+    pi = ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])
+    kat = {7: [([0, 0, 0, 0], [0, 0], [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+               ([0xffffffff] * 4, [0xffffffff] * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+               (*pi, [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a])],
+           10: [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+                ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+                (*pi, [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]}
+    for rounds, vectors in kat.items():
+        for ctr, key, want in vectors:
+            assert list(O.philox4x32(ctr, key, rounds)) == want, rounds
+    assert O.RESET_PHILOX_ROUNDS == 7 and list(O.philox4x32(*pi)) == kat[7][2][2]       # the default = the reset's
 
 
 def test_notebook_known_answers(O):
