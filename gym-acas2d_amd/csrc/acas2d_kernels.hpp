@@ -528,29 +528,17 @@ __device__ __forceinline__ void store_chunk(Vec<T, W>* dst, const Vec<T, W>& v);
 // `e` / `i0`: the element index the same value was read at.
 template <typename T, typename U>
 __device__ __forceinline__ void put_env(const State<T>& s, U* base, int e, U v) {
-#ifdef ACAS2D_STATE_PLAIN
-    base[e + s.w_env] = v;
-#else
     __builtin_nontemporal_store(v, base + (e + s.w_env));
-#endif
 }
 template <typename T>
 __device__ __forceinline__ void put_trf1(const State<T>& s, T* base, int i, T v) {
-#ifdef ACAS2D_STATE_PLAIN
-    base[i + s.w_trf] = v;
-#else
     __builtin_nontemporal_store(v, base + (i + s.w_trf));
-#endif
 }
 template <typename T, int C>
 __device__ __forceinline__ void put_trf(const State<T>& s, T* base, int i0, const Vec<T, C>& v) {
     Vec<T, C>* dst = reinterpret_cast<Vec<T, C>*>(base + (i0 + s.w_trf));
-#ifdef ACAS2D_STATE_PLAIN
-    *dst = v;
-#else
     if constexpr ((C & (C - 1)) == 0) store_chunk<T, C>(dst, v);
     else *dst = v;                                          // 3 aircraft per lane: one 12- / 24-byte store
-#endif
 }
 
 // ---- one env's player, as every lane of its group sees it ------------------------------------------
@@ -833,6 +821,8 @@ __device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int i0)
     // headings and speeds first: sin / cos and v dt start while the positions are still landing
     t.psi = *reinterpret_cast<const V*>(s.trf_psi + i0);
     t.v = *reinterpret_cast<const V*>(s.trf_v + i0);
+    // (non-temporal LOADS of the positions measured slower in round 3: 5.55 against 5.21 us per launch, 9.1 against 7.0 at
+    //  131 072 envs -- profiles/r03_ab_partial_double_buffer_nt_loads_shapes.txt)
     t.x = *reinterpret_cast<const V*>(s.trf_x + i0);
     t.y = *reinterpret_cast<const V*>(s.trf_y + i0);
     return t;

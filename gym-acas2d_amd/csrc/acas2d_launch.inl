@@ -85,7 +85,7 @@ static int write_offsets(const Acas2dState* st, const Acas2dState* out, bool aut
     }
     const int64_t lim = 0x7fffffffLL - n_envs * (int64_t)n_traffic - 64;
     const int64_t ad = d < 0 ? -d : d, adt = dt < 0 ? -dt : dt;
-    if (ad < n_envs || adt < n_envs * (int64_t)n_traffic || ad > lim || adt > lim) {
+    if ((ad != 0 && ad < n_envs) || (adt != 0 && adt < n_envs * (int64_t)n_traffic) || ad > lim || adt > lim) {   // (either group may stay in place)
         set_error("acas2d_step: state_out overlaps state, or lies more than 2^31 elements away");
         return ACAS2D_EINVAL;
     }

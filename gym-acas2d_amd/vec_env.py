@@ -167,8 +167,9 @@ class ACAS2DVecEnv:
 
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         self._cstates = []
+        self._db = set(self._gen) if self._gen["own_x"].shape[0] == 2 else set()      # the double-buffered arrays
         for gen in range(G):                # one Acas2dState per generation; everything else is shared
-            self._cstates.append(native.CState(*[ptr(self._gen[n][gen] if n in self._gen else getattr(self, n))
+            self._cstates.append(native.CState(*[ptr(self._gen[n][gen if n in self._db else 0] if n in self._gen else getattr(self, n))
                                                  for n, _ in native.CState._fields_]))
         self._cio = native.CStepIO(ptr(self._actions), ptr(self._obs), ptr(self._reward), ptr(self._done),
                                    ptr(self._outcome), ptr(self._term_obs), ptr(self._ep_return),
@@ -204,8 +205,9 @@ class ACAS2DVecEnv:
             if not self.double_buffer:
                 raise RuntimeError("align_generation(%d) on an env that steps in place" % g)
             with torch.cuda.device(self.device):
-                for t in self._gen.values():
-                    t[g].copy_(t[self._cur])
+                for n, t in self._gen.items():
+                    if n in self._db:
+                        t[g].copy_(t[self._cur])
             self._cur = g
 
     def set_double_buffer(self, flag):
@@ -451,13 +453,13 @@ class ACAS2DVecEnv:
         return out
 
     # the per-step arrays: views of the live generation
-    own_x = property(lambda self: self._gen["own_x"][self._cur])
-    own_y = property(lambda self: self._gen["own_y"][self._cur])
-    own_psi = property(lambda self: self._gen["own_psi"][self._cur])
-    trf_x = property(lambda self: self._gen["trf_x"][self._cur])
-    trf_y = property(lambda self: self._gen["trf_y"][self._cur])
-    steps = property(lambda self: self._gen["steps"][self._cur])
-    total_reward = property(lambda self: self._gen["total_reward"][self._cur])
+    own_x = property(lambda self: self._gen["own_x"][self._cur if "own_x" in self._db else 0])
+    own_y = property(lambda self: self._gen["own_y"][self._cur if "own_y" in self._db else 0])
+    own_psi = property(lambda self: self._gen["own_psi"][self._cur if "own_psi" in self._db else 0])
+    trf_x = property(lambda self: self._gen["trf_x"][self._cur if "trf_x" in self._db else 0])
+    trf_y = property(lambda self: self._gen["trf_y"][self._cur if "trf_y" in self._db else 0])
+    steps = property(lambda self: self._gen["steps"][self._cur if "steps" in self._db else 0])
+    total_reward = property(lambda self: self._gen["total_reward"][self._cur if "total_reward" in self._db else 0])
 
     @property
     def actions_buffer(self):
