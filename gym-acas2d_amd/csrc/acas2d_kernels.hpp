@@ -474,7 +474,7 @@ __device__ __forceinline__ int64_t remap_block(uint32_t trailing = 0u) {
 // generator Crush-resistant (ten is its default, with a safety margin this use does not need: the words only place
 // aircraft).  A round is two dependent v_mad_u64_u32 on the wave that resets an env, i.e. on the launch's critical
 // path: 10 -> 7 rounds measured 5.43 -> 5.22 us per launch at 65 536 x 8 (tools/ab.sh, one box).  The CPU checker of the
-// test suite draws with the same seven rounds; both are pinned by the published vectors (tests/test_oracle_golden.py).
+// test suite draws with the same seven rounds; both are pinned by the published vectors (the known-answer test under tests/).
 struct U4 { uint32_t x, y, z, w; };
 #ifndef ACAS2D_PHILOX_ROUNDS
 #define ACAS2D_PHILOX_ROUNDS 7           // anything else: diagnostic builds only (the reset chain's latency knob)
