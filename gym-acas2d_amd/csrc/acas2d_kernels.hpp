@@ -1461,11 +1461,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     const State<T> s = rebase(s_in, e_wave, N);    // everything below indexes envs by `el`
     const StepIO<T> io0 = rebase(io_arg, e_wave, D);
     // per wave: the observation tile, then (HANDOFF) the reset slots (SlotLayout) / one 4N+1-value scratch
-#ifdef ACAS2D_NO_HANDOFF                             // A/B builds only: flush first, reset after, re-flush the row
-    constexpr bool HANDOFF = PACKED && AUTO_RESET && ROLLOUT;
-#else
     constexpr bool HANDOFF = PACKED && AUTO_RESET;   // finished envs are reset BEFORE the wave's stores
-#endif
     T* tile = reinterpret_cast<T*>(lds_raw) + wib * tile_elems;
     T* row = tile + el * D;
     T* scratch = HANDOFF ? tile + (EPW * D + 3) / 4 * 4 : nullptr;     // 16-byte aligned within the tile allocation
