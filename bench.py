@@ -454,6 +454,8 @@ def main():
                              "envs_per_gpu": E, "n_traffic": N, "launch": args.launch, "steps_per_graph": chunk,
                              "state_buffers": "double (read generation g, write 1 - g)" if getattr(env, "double_buffer", False)
                                               else "in place",
+                             "state_layout": "consecutive rows (all loads through preloaded base pointers)"
+                                             if getattr(env, "consecutive_layout", False) else "separate arrays",
                              "warmup_graph_replays": spin_replays,
                              "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"],
                              "grid_blocks": geo["grid_blocks"],

@@ -38,6 +38,8 @@ Shape choose_shape(int n, int elem_size) {
 
 template <typename T>
 int shape_geometry(int64_t n_envs, int32_t n_traffic, int32_t* lanes, int32_t* per_lane, int64_t* grid);
+template <typename T>
+int state_consecutive(const Acas2dState* st, int64_t n_envs, int32_t n_traffic);
 
 }  // namespace acas2d
 
@@ -97,6 +99,10 @@ int acas2d_reset_f64(const Acas2dConfig* cfg, const Acas2dState* state, const ui
     return launch_reset<double>(cfg, state, mask, obs, do_init, seed, env_offset, n_envs, n_traffic, (hipStream_t)stream);
 }
 
+int acas2d_state_is_consecutive(const Acas2dState* state, int64_t n_envs, int32_t n_traffic, int32_t elem_size) {
+    return elem_size == 4 ? state_consecutive<float>(state, n_envs, n_traffic)
+                          : (elem_size == 8 ? state_consecutive<double>(state, n_envs, n_traffic) : 0);
+}
 int acas2d_launch_geometry(int64_t n_envs, int32_t n_traffic, int32_t elem_size, int32_t* lanes_per_env,
                            int32_t* traffic_per_lane, int32_t* block_threads, int64_t* grid_blocks) {
     if (n_traffic < 1 || n_envs < 0 || (elem_size != 4 && elem_size != 8)) {

@@ -13,6 +13,7 @@ template int launch_rollout_policy<float>(const Acas2dConfig*, const Acas2dState
 template int launch_collect<float>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, const Acas2dActorCritic*, const void*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int launch_reset<float>(const Acas2dConfig*, const Acas2dState*, const uint8_t*, void*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int shape_geometry<float>(int64_t, int32_t, int32_t*, int32_t*, int64_t*);
+template int state_consecutive<float>(const Acas2dState*, int64_t, int32_t);
 }
 
 #ifdef ACAS2D_STAMPS

@@ -13,4 +13,5 @@ template int launch_rollout_policy<double>(const Acas2dConfig*, const Acas2dStat
 template int launch_collect<double>(const Acas2dConfig*, const Acas2dState*, const Acas2dStepIO*, const Acas2dActorCritic*, const void*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int launch_reset<double>(const Acas2dConfig*, const Acas2dState*, const uint8_t*, void*, int32_t, uint64_t, int64_t, int64_t, int32_t, hipStream_t);
 template int shape_geometry<double>(int64_t, int32_t, int32_t*, int32_t*, int64_t*);
+template int state_consecutive<double>(const Acas2dState*, int64_t, int32_t);
 }

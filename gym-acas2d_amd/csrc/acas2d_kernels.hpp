@@ -463,11 +463,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 // XCD-aware block remap: blocks are dealt round-robin over the 8 XCDs, so give each XCD one
 // contiguous eighth of the env range (its L2 then sees whole cache lines and the same envs on
 // every step).  Speed only -- any placement is correct.
-__device__ __forceinline__ int64_t remap_block(uint32_t trailing = 0u) {
-    const uint32_t nb = gridDim.x - trailing, b = blockIdx.x;        // `trailing` last workgroups have another role
-    if ((nb & 7u) == 0u) return (int64_t)(b & 7u) * (nb >> 3) + (b >> 3);
+__device__ __forceinline__ uint32_t remap_block_of(uint32_t nb) {
+    const uint32_t b = blockIdx.x;
+    if ((nb & 7u) == 0u) return (b & 7u) * (nb >> 3) + (b >> 3);
     return b;
 }
+__device__ __forceinline__ int64_t remap_block() { return remap_block_of(gridDim.x); }
 
 // ---- Philox4x32-7 counter-based reset RNG -----------------------------------------------------------
 // Seven rounds: the fewest for which Random123 (Salmon et al., SC'11) publishes known-answer vectors and reports the
@@ -815,17 +816,21 @@ struct Traffic {
     Vec<T, C> x, y, psi, v;
 };
 template <typename T, int C>
-__device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int i0) {
+__device__ __forceinline__ Traffic<T, C> load_traffic(const T* trf_psi, const T* trf_v, const T* trf_x, const T* trf_y, int i0) {
     using V = Vec<T, C>;
     Traffic<T, C> t;
     // headings and speeds first: sin / cos and v dt start while the positions are still landing
-    t.psi = *reinterpret_cast<const V*>(s.trf_psi + i0);
-    t.v = *reinterpret_cast<const V*>(s.trf_v + i0);
+    t.psi = *reinterpret_cast<const V*>(trf_psi + i0);
+    t.v = *reinterpret_cast<const V*>(trf_v + i0);
     // (non-temporal LOADS of the positions measured slower in round 3: 5.55 against 5.21 us per launch, 9.1 against 7.0 at
     //  131 072 envs -- profiles/r03_ab_partial_double_buffer_nt_loads_shapes.txt)
-    t.x = *reinterpret_cast<const V*>(s.trf_x + i0);
-    t.y = *reinterpret_cast<const V*>(s.trf_y + i0);
+    t.x = *reinterpret_cast<const V*>(trf_x + i0);
+    t.y = *reinterpret_cast<const V*>(trf_y + i0);
     return t;
+}
+template <typename T, int C>
+__device__ __forceinline__ Traffic<T, C> load_traffic(const State<T>& s, int i0) {
+    return load_traffic<T, C>(s.trf_psi, s.trf_v, s.trf_x, s.trf_y, i0);
 }
 
 // game.py:162-166 minimum_separation() as action() logs it (game.py:236-237): the player has moved, the
@@ -1423,43 +1428,45 @@ __device__ __forceinline__ float policy_action(const PolicyW& pw, const float (&
 // observation and the log-probability of the draw are stored per step, the env is stepped with the clipped action, and
 // a non-finite observation entry reaches the networks as 0 (the reference's NaN d_cpa in exact parallel flight).
 template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, bool ROLLOUT, bool POLICY = false,
-          bool SAMPLE = false>
-__global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
+          bool SAMPLE = false, bool ARENA = false>
+__global__ __launch_bounds__(kBlock) void step_kernel(const T* a0, const T* a1, const T* a2, const T* a3, const T* a4,
+                                                      const T* a5, int32_t e_n_envs, int32_t tile_elems,
+                                                      Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
-                                                      int64_t env_offset, int64_t n_envs, int N_arg,
-                                                      int tile_elems, int n_steps, PolicyW pw) {
+                                                      int64_t env_offset, int N_arg, int n_steps, PolicyW pw) {
     static_assert(!ROLLOUT || (AUTO_RESET && PACKED), "rollout: auto-reset semantics, packed shapes");
     static_assert(!POLICY || (ROLLOUT && G == 1), "in-kernel policy: rollout mode, one lane per env");
     static_assert(!SAMPLE || POLICY, "sampling needs the in-kernel policy");
     constexpr int NS = PACKED ? C * G : 0;         // packed shapes: n_traffic is a compile-time constant
     const int N = PACKED ? NS : N_arg;
     constexpr int EPW = 64 / G;                    // envs per wavefront
-    // Everything the loads below need from the kernel arguments, requested in ONE scalar-load round
-    // trip: left alone, hipcc fetches the grid size, then n_envs (early exit), then the pointers, each
-    // behind its own s_waitcnt -- three dependent round trips before the first global load.
-    {
-        const uint32_t nb = gridDim.x;
-        asm volatile("" :: "s"(nb), "s"(n_envs), "s"(s_arg.own_x), "s"(s_arg.own_y), "s"(s_arg.own_psi), "s"(s_arg.own_v),
-                     "s"(s_arg.goal_x), "s"(s_arg.goal_y), "s"(s_arg.trf_x), "s"(s_arg.trf_y), "s"(s_arg.trf_psi),
-                     "s"(s_arg.trf_v), "s"(s_arg.steps), "s"(s_arg.total_reward), "s"(s_arg.episode), "s"(io_arg.actions),
-                     "s"(tile_elems), "s"(s_arg.w_env), "s"(s_arg.w_trf));
-    }
+    // The FIRST 14 dwords of the kernel arguments (a0 .. a5, the env count, the tile size) are preloaded into SGPRs by the
+    // command processor (gfx950 kernarg preload, KFLAGS in the Makefile): loads through them leave with the wave's first
+    // instructions instead of behind a scalar-load round trip to the argument segment (~0.27 us, all waves of a launch
+    // miss together).  The grid size follows from the env count (geometry_for), so nothing of the launch geometry is
+    // fetched either.  Six pointers do not name fourteen input arrays, so:
+    //   ARENA   (launch_step_impl found the state laid out as consecutive [k][E] rows, as the Python host allocates it)
+    //           a0 = own_x (then own_y, own_psi, total_reward, steps), a1 = own_v (then goal_x, goal_y, episode),
+    //           a2 = trf_x (then trf_y), a3 = trf_psi (then trf_v), a4 = actions: EVERY load leaves at once;
+    //   else    a0 .. a5 = trf_x, trf_y, trf_psi, trf_v, own_x, own_y: the bulk of the bytes leaves at once, the rest
+    //           behind the round trip.
+    static_assert(!ARENA || (sizeof(T) == 4 && PACKED && AUTO_RESET && !ROLLOUT), "arena launches: the float32 per-step auto-reset kernel");
+    // A wavefront issues one instruction per four cycles whatever its kind, and every instruction in front of the first
+    // load is on the launch's critical path: env indices are 32-bit here (n_envs < 2^31, geometry_for).
+    const uint32_t E32 = (uint32_t)e_n_envs;
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1), el = lane / G;   // lane in group, env in wave
     const int wib = wave_in_block();
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int64_t wave = remap_block() * kWavesPerBlock + wib;
-    const int64_t e_wave = wave * EPW;             // first env of this wave (scalar)
-    if (e_wave >= n_envs) return;                  // whole wave idle
+    constexpr uint32_t kEnvsPerBlock = EPW * kWavesPerBlock;
+    const uint32_t wave32 = remap_block_of((E32 + (kEnvsPerBlock - 1u)) / kEnvsPerBlock) * kWavesPerBlock + (uint32_t)wib;
+    const uint32_t e_wave32 = wave32 * EPW;        // first env of this wave (scalar); < 2^31 + 128
+    if (e_wave32 >= E32) return;                   // whole wave idle
     const int D = 5 + 3 * N;
-    const int n_rows = (int)((n_envs - e_wave) < EPW ? (n_envs - e_wave) : EPW);
+    const int n_rows = (int)((E32 - e_wave32) < (uint32_t)EPW ? (E32 - e_wave32) : (uint32_t)EPW);
     const bool active = el < n_rows;               // whole groups are active or not
-    State<T> s_in = s_arg;
-    // only the per-step auto-reset launch takes a second state generation (launch_step_impl); elsewhere the offsets are
-    // compile-time zeros and cost no registers
-    if constexpr (ROLLOUT || !AUTO_RESET) { s_in.w_env = 0; s_in.w_trf = 0; }
-    const State<T> s = rebase(s_in, e_wave, N);    // everything below indexes envs by `el`
-    const StepIO<T> io0 = rebase(io_arg, e_wave, D);
+    const int64_t n_envs = E32, e_wave = e_wave32, wave = wave32;
+    (void)wave;
     // per wave: the observation tile, then (HANDOFF) the reset slots (SlotLayout) / one 4N+1-value scratch
     constexpr bool HANDOFF = PACKED && AUTO_RESET;   // finished envs are reset BEFORE the wave's stores
     T* tile = reinterpret_cast<T*>(lds_raw) + wib * tile_elems;
@@ -1482,18 +1489,80 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
     // kernel wait for all stores issued in between (s_waitcnt vmcnt(0) before the tile flush).
     const bool run = PACKED ? true : active;
     const int el_l = (PACKED && !active) ? 0 : el;         // the env a lane LOADS
-    if (run) {
-        // ---- every load of this lane up front: one memory round trip, all requests in flight.  The
-        // player's scalars and the action first, the traffic vectors (the bulk) last: loads return in
-        // order, so the player-side arithmetic can start while the vectors are still landing
-        // (s_waitcnt vmcnt(4), then vmcnt(0) before the first traffic instruction): 7.12 -> 7.0x us.
-        o = Own<T>{s.own_x[el_l], s.own_y[el_l], s.own_psi[el_l], s.own_v[el_l], T(0), s.goal_x[el_l], s.goal_y[el_l]};
-        steps = s.steps[el_l];
-        total = s.total_reward[el_l];
-        if constexpr (AUTO_RESET) episode = s.episode[el_l];
-        else frozen = s.status[el_l] != 0;                                 // game.py:243-245
-        if constexpr (!POLICY) action_next = io0.actions[el_l];
-        if constexpr (PACKED) tr = load_traffic<T, C>(s, el_l * N + j * C);
+    // ---- every load of this lane up front, all requests in flight at once; the loads through the preloaded pointers
+    // leave in front of the wait for the other arguments ...
+    State<T> s_in = s_arg;                                 // (fields nobody reads cost nothing)
+    const T* act_in = io_arg.actions;
+    if constexpr (ARENA) {
+        const int64_t E = n_envs, EN = n_envs * N;
+        T* m = const_cast<T*>(a0);
+        T* c = const_cast<T*>(a1);
+        s_in.own_x = m; s_in.own_y = m + E; s_in.own_psi = m + 2 * E; s_in.total_reward = m + 3 * E;
+        s_in.steps = reinterpret_cast<int32_t*>(m + 4 * E);
+        s_in.own_v = c; s_in.goal_x = c + E; s_in.goal_y = c + 2 * E; s_in.episode = reinterpret_cast<uint32_t*>(c + 3 * E);
+        s_in.trf_x = const_cast<T*>(a2); s_in.trf_y = s_in.trf_x + EN;
+        s_in.trf_psi = const_cast<T*>(a3); s_in.trf_v = s_in.trf_psi + EN;
+        s_in.trace = nullptr;
+        act_in = a4;
+    } else {
+        s_in.trf_x = const_cast<T*>(a0); s_in.trf_y = const_cast<T*>(a1); s_in.trf_psi = const_cast<T*>(a2);
+        s_in.trf_v = const_cast<T*>(a3); s_in.own_x = const_cast<T*>(a4); s_in.own_y = const_cast<T*>(a5);
+    }
+    // only the per-step auto-reset launch takes a second state generation (launch_step_impl); elsewhere the offsets are
+    // compile-time zeros and cost no registers
+    if constexpr (ROLLOUT || !AUTO_RESET) { s_in.w_env = 0; s_in.w_trf = 0; }
+    T ox = T(0), oy = T(0);
+    if constexpr (ARENA) {
+        // Unmodified preloaded bases + 32-bit per-lane byte offsets (launch_step_impl checked that they fit): one VALU add
+        // per array instead of four scalar ones.  The player's scalars and the action first, the traffic vectors (the
+        // bulk) last: loads return in order, so the player-side arithmetic can start while the vectors are landing.
+        if (run) {
+            const uint32_t ie = e_wave32 + (uint32_t)el_l;                 // this lane's env
+            const auto at = [](const T* base, uint32_t elem) {
+                return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)(elem * 4u));
+            };
+            ox = *at(a0, ie); oy = *at(a0, ie + E32);
+            o = Own<T>{ox, oy, *at(a0, ie + 2u * E32), *at(a1, ie), T(0), *at(a1, ie + E32), *at(a1, ie + 2u * E32)};
+            steps = *reinterpret_cast<const int32_t*>(at(a0, ie + 4u * E32));
+            total = *at(a0, ie + 3u * E32);
+            episode = *reinterpret_cast<const uint32_t*>(at(a1, ie + 3u * E32));
+            action_next = *at(a4, ie);
+            using V = Vec<T, C>;
+            const uint32_t it = ie * (uint32_t)N + (uint32_t)(j * C), EN32 = E32 * (uint32_t)N;
+            tr.psi = *reinterpret_cast<const V*>(at(a3, it));
+            tr.v = *reinterpret_cast<const V*>(at(a3, it + EN32));
+            tr.x = *reinterpret_cast<const V*>(at(a2, it));
+            tr.y = *reinterpret_cast<const V*>(at(a2, it + EN32));
+        }
+    } else if (run) {
+        if constexpr (PACKED)
+            tr = load_traffic<T, C>(s_in.trf_psi + e_wave * N, s_in.trf_v + e_wave * N, s_in.trf_x + e_wave * N,
+                                    s_in.trf_y + e_wave * N, el_l * N + j * C);
+        ox = (s_in.own_x + e_wave)[el_l]; oy = (s_in.own_y + e_wave)[el_l];
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // ... and stay there: nothing below is scheduled above them
+    // everything else the loads (ARENA: the stores) need from the kernel arguments, requested in ONE scalar-load round
+    // trip (left alone, hipcc fetches them one by one, each behind its own s_waitcnt)
+    if constexpr (ARENA)
+        asm volatile("" :: "s"(s_arg.w_env), "s"(s_arg.w_trf), "s"(io_arg.obs), "s"(io_arg.reward), "s"(io_arg.done),
+                     "s"(io_arg.outcome) : "memory");
+    else
+        asm volatile("" :: "s"(s_arg.own_psi), "s"(s_arg.own_v), "s"(s_arg.goal_x), "s"(s_arg.goal_y),
+                     "s"(s_arg.steps), "s"(s_arg.total_reward), "s"(s_arg.episode), "s"(io_arg.actions),
+                     "s"(s_arg.w_env), "s"(s_arg.w_trf) : "memory");
+    const State<T> s = rebase(s_in, e_wave, N);            // everything below indexes envs by `el`
+    StepIO<T> io_in = io_arg;
+    io_in.actions = act_in;
+    const StepIO<T> io0 = rebase(io_in, e_wave, D);
+    if constexpr (!ARENA) {
+        if (run) {
+            o = Own<T>{ox, oy, s.own_psi[el_l], s.own_v[el_l], T(0), s.goal_x[el_l], s.goal_y[el_l]};
+            steps = s.steps[el_l];
+            total = s.total_reward[el_l];
+            if constexpr (AUTO_RESET) episode = s.episode[el_l];
+            else frozen = s.status[el_l] != 0;                             // game.py:243-245
+            if constexpr (!POLICY) action_next = io0.actions[el_l];
+        }
     }
 
     // Launch constants into VGPRs only now, AFTER the loads are in flight: pinned() is ~25 v_movs
@@ -1509,7 +1578,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
                      "s"(rp.t0_heading_base), "s"(rp.t0_heading_step), "s"(rp.t0_heading_jitter), "s"(rp.tn_x_max),
                      "s"(rp.tn_y_max), "s"(rp.speed_factor_min), "s"(rp.speed_factor_max), "s"(rp.airspeed),
                      "s"(rp.d_goal0), "s"(rp.h_goal0), "s"(rp.d_dev0),
-                     "s"(k0), "s"(k1), "s"(io_arg.ep_steps));
+                     "s"(k0), "s"(k1), "s"(io_arg.ep_steps), "s"(env_offset));
     }
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
     const int T_steps = ROLLOUT ? n_steps : 1;
@@ -1645,6 +1714,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(Params<T> p_arg, StepReset
             constexpr bool SLOTTED = ResetSlots<NS>::SLOTS >= 2;      // N + 1 <= 32: several envs per pass
             if constexpr (SLOTTED) {
                 using SL = SlotLayout<T, NS>;
+#ifdef ACAS2D_RESET_PRIO
+                if (dm) __builtin_amdgcn_s_setprio(3);
+#endif
                 while (dm) {
                     wave_lds_fence();                     // every row of the tile is complete
                     const unsigned long long taken =

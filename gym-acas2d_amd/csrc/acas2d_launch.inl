@@ -107,7 +107,7 @@ template <typename T>
 static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry* g) {
     const int64_t epw = 64 / sh.G, envs_per_block = epw * kWavesPerBlock;
     const int64_t blocks = (n_envs + envs_per_block - 1) / envs_per_block;
-    if (blocks > 0x7fffffffLL) { set_error("n_envs = %lld exceeds the grid limit", (long long)n_envs); return ACAS2D_EINVAL; }
+    if (blocks > 0x7fffffffLL || n_envs > 0x7fffffffLL) { set_error("n_envs = %lld exceeds the launch limit", (long long)n_envs); return ACAS2D_EINVAL; }
     const int W = 16 / (int)sizeof(T);
     // per wave: the observation tile, then the reset slots (SlotLayout<T, N> in the kernels; packed shapes with
     // N + 1 <= 32) or one 4N+1-value hand-off scratch (the other packed shapes), everything 16-byte aligned
@@ -129,16 +129,46 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
     return ACAS2D_OK;
 }
 
+// The step kernel's first 14 argument dwords are what the command processor preloads into SGPRs (see step_kernel):
+// six pointers, the env count, the tile size.
+#define ACAS2D_EARLY_ARGS(s, n_envs, g) \
+    (s).trf_x, (s).trf_y, (s).trf_psi, (s).trf_v, (s).own_x, (s).own_y, (int32_t)(n_envs), (int32_t)(g).tile_elems
+
+// "Arena" layout of a float32 state: the per-env arrays a step reads are consecutive [k][E] rows -- own_x, own_y,
+// own_psi, total_reward, steps / own_v, goal_x, goal_y, episode -- and so are the traffic arrays -- trf_x, trf_y /
+// trf_psi, trf_v ([k][E][N]).  Five preloaded base pointers (the four blocks and the actions) then name every input of
+// the step, and ALL of a wavefront's loads leave before its first scalar-load round trip (step_kernel<..., ARENA>).
+// `ACAS2DVecEnv` allocates its float32 state this way; any other layout takes the general kernel, same results.
+template <typename T>
+static bool arena_layout(const State<T>& s, int64_t E, int N) {
+    if (sizeof(T) != 4 || getenv("ACAS2D_NO_ARENA")) return false;
+    const int64_t EN = E * N;
+    if (8 * EN >= (1LL << 32) || 20 * E >= (1LL << 32)) return false;      // the kernel's 32-bit byte offsets
+    return s.own_y == s.own_x + E && s.own_psi == s.own_x + 2 * E && s.total_reward == s.own_x + 3 * E &&
+           (const void*)s.steps == (const void*)(s.own_x + 4 * E) &&
+           s.goal_x == s.own_v + E && s.goal_y == s.own_v + 2 * E && (const void*)s.episode == (const void*)(s.own_v + 3 * E) &&
+           s.trf_y == s.trf_x + EN && s.trf_v == s.trf_psi + EN;
+}
+
 template <typename T, bool FAST, int C, int G, bool PACKED>
 static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, const Params<T>& p,
                        const ResetParamsT<T>& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
                        int64_t env_offset, int64_t n_envs, int N) {
+    if constexpr (PACKED && sizeof(T) == 4) {
+        if (auto_reset && arena_layout<T>(s, n_envs, N)) {
+            hipLaunchKernelGGL((step_kernel<T, C, G, true, true, FAST, false, false, false, true>), dim3(g.grid), dim3(g.block),
+                               g.lds_bytes, stream, (const T*)s.own_x, (const T*)s.own_v, (const T*)s.trf_x, (const T*)s.trf_psi,
+                               io.actions, (const T*)nullptr, (int32_t)n_envs, (int32_t)g.tile_elems,
+                               p, rp, s, io, k0, k1, env_offset, N, 1, PolicyW{});
+            return;
+        }
+    }
     if (auto_reset)
         hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, true, FAST, false>), dim3(g.grid), dim3(g.block), g.lds_bytes, stream,
-                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
+                           ACAS2D_EARLY_ARGS(s, n_envs, g), p, rp, s, io, k0, k1, env_offset, N, 1, PolicyW{});
     else
         hipLaunchKernelGGL((step_kernel<T, C, G, PACKED, false, FAST, false>), dim3(g.grid), dim3(g.block), g.lds_bytes, stream,
-                           p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, 1, PolicyW{});
+                           ACAS2D_EARLY_ARGS(s, n_envs, g), p, rp, s, io, k0, k1, env_offset, N, 1, PolicyW{});
 }
 
 template <typename T, bool FAST, int C, int G>
@@ -146,7 +176,7 @@ static void rollout_shape(const Geometry& g, hipStream_t stream, const Params<T>
                           const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1, int64_t env_offset,
                           int64_t n_envs, int N, int n_steps) {
     hipLaunchKernelGGL((step_kernel<T, C, G, true, true, FAST, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes, stream,
-                       p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, PolicyW{});
+                       ACAS2D_EARLY_ARGS(s, n_envs, g), p, rp, s, io, k0, k1, env_offset, N, n_steps, PolicyW{});
 }
 
 // the same with the SB3 actor evaluated in the kernel (thread-per-env shapes only)
@@ -156,10 +186,10 @@ static void policy_shape(const Geometry& g, hipStream_t stream, const Params<T>&
                          int64_t n_envs, int N, int n_steps, const PolicyW& pw, bool sample) {
     if (sample)
         hipLaunchKernelGGL((step_kernel<T, C, 1, true, true, FAST, true, true, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes,
-                           stream, p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, pw);
+                           stream, ACAS2D_EARLY_ARGS(s, n_envs, g), p, rp, s, io, k0, k1, env_offset, N, n_steps, pw);
     else
         hipLaunchKernelGGL((step_kernel<T, C, 1, true, true, FAST, true, true>), dim3(g.grid), dim3(kBlock), g.lds_bytes,
-                           stream, p, rp, s, io, k0, k1, env_offset, n_envs, N, g.tile_elems, n_steps, pw);
+                           stream, ACAS2D_EARLY_ARGS(s, n_envs, g), p, rp, s, io, k0, k1, env_offset, N, n_steps, pw);
 }
 
 template <typename T, bool FAST, int C, int G, bool PACKED>
@@ -389,6 +419,16 @@ int launch_reset(const Acas2dConfig* cfg, const Acas2dState* st, const uint8_t* 
                  hipStream_t stream) {
     return fast_math<T>(cfg) ? launch_reset_impl<T, true>(cfg, st, mask, obs, do_init, seed, env_offset, n_envs, n_traffic, stream)
                              : launch_reset_impl<T, kFast>(cfg, st, mask, obs, do_init, seed, env_offset, n_envs, n_traffic, stream);
+}
+
+// 1 when acas2d_step_* (auto-reset) would take the kernel whose loads all go through preloaded base pointers for this
+// state: float32, a packed work shape, the consecutive layout of arena_layout()
+template <typename T>
+int state_consecutive(const Acas2dState* st, int64_t n_envs, int32_t n_traffic) {
+    if (!state_complete(st) || n_envs <= 0 || n_traffic < 1) return 0;
+    Shape sh;
+    if (resolve_shape<T>(n_traffic, &sh) != ACAS2D_OK || !sh.packed) return 0;
+    return arena_layout<T>(make_state<T>(*st), n_envs, n_traffic) ? 1 : 0;
 }
 
 template <typename T>

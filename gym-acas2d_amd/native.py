@@ -8,7 +8,7 @@ from .config import CConfig
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libacas2d_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 AUTO_RESET = 1
 
@@ -51,7 +51,8 @@ class CPpoUpdate(C.Structure):
 EXPORTS = ("acas2d_abi_version", "acas2d_config_size", "acas2d_state_size", "acas2d_last_error", "acas2d_step_f32",
            "acas2d_step_f64", "acas2d_rollout_f32", "acas2d_rollout_f64", "acas2d_rollout_policy_f32",
            "acas2d_rollout_policy_f64", "acas2d_collect_f32", "acas2d_collect_f64", "acas2d_ppo_workspace_floats",
-           "acas2d_ppo_update_f32", "acas2d_reset_f32", "acas2d_reset_f64", "acas2d_launch_geometry")
+           "acas2d_ppo_update_f32", "acas2d_reset_f32", "acas2d_reset_f64", "acas2d_launch_geometry",
+           "acas2d_state_is_consecutive")
 
 
 class NativeLibraryError(RuntimeError):
@@ -122,6 +123,8 @@ def lib():
         f.restype = C.c_int
         f.argtypes = [C.POINTER(CConfig), C.POINTER(CState), C.c_void_p, C.c_void_p, C.c_int32,
                       C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+    L.acas2d_state_is_consecutive.restype = C.c_int
+    L.acas2d_state_is_consecutive.argtypes = [C.POINTER(CState), C.c_int64, C.c_int32, C.c_int32]
     L.acas2d_launch_geometry.restype = C.c_int
     L.acas2d_launch_geometry.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]

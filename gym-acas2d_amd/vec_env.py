@@ -145,14 +145,25 @@ class ACAS2DVecEnv:
             raise ValueError("double_buffer needs auto_reset=True (the latching step leaves frozen traffic unwritten)")
         G = 2 if self.double_buffer else 1
         # generations of the per-step arrays ([G, E] / [G, E, N]; own_x ... total_reward are properties naming the live one)
-        self._gen = {"own_x": z(G, E), "own_y": z(G, E), "own_psi": z(G, E), "trf_x": z(G, E, N), "trf_y": z(G, E, N),
-                     "steps": z(G, E, dt=torch.int32), "total_reward": z(G, E)}
+        if dtype == torch.float32:
+            # "arena" layout (include/acas2d.h, Acas2dState): the arrays a step reads are consecutive [k][E] rows of four
+            # blocks, so five base pointers name every input and the step launch takes the kernel whose loads all leave
+            # before its first scalar-load round trip.  Views below; a generation is a whole [5][E] / [2][E][N] block.
+            mut, tmut, const, tconst = z(G, 5, E), z(G, 2, E, N), z(4, E), z(2, E, N)
+            self._gen = {"own_x": mut[:, 0], "own_y": mut[:, 1], "own_psi": mut[:, 2], "total_reward": mut[:, 3],
+                         "steps": mut[:, 4].view(torch.int32), "trf_x": tmut[:, 0], "trf_y": tmut[:, 1]}
+            self.own_v, self.goal_x, self.goal_y = const[0], const[1], const[2]
+            self.episode = const[3].view(torch.int32)  # bit pattern of the u32 counter
+            self.trf_psi, self.trf_v = tconst[0], tconst[1]
+        else:
+            self._gen = {"own_x": z(G, E), "own_y": z(G, E), "own_psi": z(G, E), "trf_x": z(G, E, N), "trf_y": z(G, E, N),
+                         "steps": z(G, E, dt=torch.int32), "total_reward": z(G, E)}
+            self.own_v = z(E)
+            self.goal_x, self.goal_y = z(E), z(E)
+            self.trf_psi, self.trf_v = z(E, N), z(E, N)
+            self.episode = z(E, dt=torch.int32)        # bit pattern of the u32 counter
         self._cur = 0
-        self.own_v = z(E)
-        self.goal_x, self.goal_y = z(E), z(E)
-        self.trf_psi, self.trf_v = z(E, N), z(E, N)
         self.status = z(E, dt=torch.uint8)
-        self.episode = z(E, dt=torch.int32)            # bit pattern of the u32 counter
         if record_trace and auto_reset:
             raise ValueError("record_trace needs auto_reset=False (the reference's single-env semantics)")
         self.trace = z(E, len(TRACE_COLUMNS) + 3) if record_trace else None
@@ -191,6 +202,13 @@ class ACAS2DVecEnv:
     def _cstate(self):
         """Acas2dState of the LIVE generation (what reset / rollout / collect act on, in place)."""
         return self._cstates[self._cur]
+
+    @property
+    def consecutive_layout(self):
+        """True when step() launches the kernel whose loads all go through preloaded base pointers (include/acas2d.h,
+        "Consecutive layout"): float32 state as allocated here, a packed work shape for n_traffic, auto_reset."""
+        return bool(self.auto_reset and self._lib.acas2d_state_is_consecutive(
+            C.byref(self._cstate), self.num_envs, self.n_traffic, 4 if self.dtype == torch.float32 else 8))
 
     @property
     def generation(self):

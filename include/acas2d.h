@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define ACAS2D_ABI_VERSION 6
+#define ACAS2D_ABI_VERSION 7
 
 /* error codes */
 #define ACAS2D_OK 0
@@ -163,6 +163,20 @@ const char *acas2d_last_error(void);  /* thread-local; valid until the next fail
  *   goal_*, trf_psi, trf_v, status, episode, trace: changed at a reset only, in place) is the SAME buffer in
  *   both structs.  Needs ACAS2D_AUTO_RESET.  A hipGraph that captures an odd number of steps must not be
  *   replayed twice in a row (each replay would read the generation the previous one also read).
+ *
+ * Consecutive layout (ABI 7; optional, detected per launch, results identical either way): when the float32 arrays a
+ *   step READS are consecutive rows of four blocks --
+ *       own_x, own_y, own_psi, total_reward, steps     T[5][E]        own_v, goal_x, goal_y, episode    T[4][E]
+ *       trf_x, trf_y                                   T[2][E][N]     trf_psi, trf_v                    T[2][E][N]
+ *   (i.e. own_y == own_x + E, ..., (void*)steps == own_x + 4 E, trf_y == trf_x + E N, ...; a second generation is then
+ *   a whole second T[5][E] / T[2][E][N] block, which satisfies state_out's contract above) -- five base pointers and the
+ *   env count name every input of the step.  gfx950 hands the first 14 dwords of a kernel's arguments to each wavefront
+ *   in registers, so the auto-reset step then issues ALL its loads with its first instructions instead of behind a
+ *   scalar-load round trip to the argument segment (65 536 x 8: 5.19 -> 5.06 us per launch, 4.36 -> 4.06 where no env
+ *   finishes).  Needs n_traffic with a packed work shape, E N < 2^29.  acas2d_state_is_consecutive() tells whether a
+ *   state qualifies; any other layout runs the general kernel.
+ *
+ * n_envs < 2^31 per call (shard beyond that: env_offset).
  */
 int acas2d_step_f32(const Acas2dConfig *cfg, const Acas2dState *state, const Acas2dState *state_out,
                     const Acas2dStepIO *io, uint32_t flags, uint64_t seed, int64_t env_offset,
@@ -301,6 +315,10 @@ int acas2d_reset_f32(const Acas2dConfig *cfg, const Acas2dState *state, const ui
 int acas2d_reset_f64(const Acas2dConfig *cfg, const Acas2dState *state, const uint8_t *mask,
                      void *obs, int32_t do_init, uint64_t seed, int64_t env_offset,
                      int64_t n_envs, int32_t n_traffic, void *stream);
+
+/* 1 if acas2d_step_* with ACAS2D_AUTO_RESET takes the consecutive-layout kernel for this state (see acas2d_step_*),
+ * else 0.  Informational (bench / tests); never an error. */
+int acas2d_state_is_consecutive(const Acas2dState *state, int64_t n_envs, int32_t n_traffic, int32_t elem_size);
 
 /*
  * Launch geometry chosen for (n_envs, n_traffic, elem_size = 4 | 8): lanes per env (power of two

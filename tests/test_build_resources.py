@@ -20,7 +20,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def test_no_kernel_spills_or_uses_scratch(unit, tmp_path):
     asm = tmp_path / (unit + ".s")
     subprocess.run([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
-                    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-ffp-contract=off", "-fno-slp-vectorize", "-S",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm",
+                    "-amdgpu-kernarg-preload-count=8", "-S",
                     "--cuda-device-only", "-o", str(asm), os.path.join(CSRC, unit)], check=True, capture_output=True)
     text = asm.read_text()
     kernels = re.findall(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", text, re.S)

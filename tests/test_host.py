@@ -75,7 +75,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol(g):
     for name in declared:
         assert hasattr(L, name), name
     assert set(g.native.EXPORTS) == declared
-    assert L.acas2d_abi_version() == g.native.ABI_VERSION == 6 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
+    assert L.acas2d_abi_version() == g.native.ABI_VERSION == 7 and L.acas2d_config_size() == C.sizeof(g.config.CConfig)
     assert int(re.search(r"#define ACAS2D_ABI_VERSION (\d+)", header).group(1)) == g.native.ABI_VERSION
 
 
@@ -133,6 +133,28 @@ def test_c_abi_argument_validation_needs_no_gpu(g):
     assert g.native.launch_geometry(10, 1)["lanes_per_env"] == 1
     assert g.native.launch_geometry(65536, 64)["lanes_per_env"] == 16
     assert L.acas2d_state_size() == C.sizeof(g.native.CState)
+    # consecutive ("arena") layout, include/acas2d.h: pointer arithmetic only, so synthetic addresses do
+    E, N, b = 1000, 8, 1 << 20
+
+    def arena(elem=4, **over):
+        f = {n: 0 for n, _ in g.native.CState._fields_}
+        for k, n in enumerate(("own_x", "own_y", "own_psi", "total_reward", "steps")):
+            f[n] = b + k * E * elem
+        for k, n in enumerate(("own_v", "goal_x", "goal_y", "episode")):
+            f[n] = 2 * b + k * E * elem
+        f["trf_x"], f["trf_y"] = 3 * b, 3 * b + E * N * elem
+        f["trf_psi"], f["trf_v"] = 4 * b, 4 * b + E * N * elem
+        f["status"], f["trace"] = 5 * b, None
+        f.update(over)
+        return g.native.CState(*[f[n] for n, _ in g.native.CState._fields_])
+
+    yes = lambda st, n=N, elem=4, e=E: L.acas2d_state_is_consecutive(C.byref(st), e, n, elem)  # noqa: E731
+    assert yes(arena()) == 1
+    assert yes(arena(own_y=b + 4 * E + 4)) == 0 and yes(arena(trf_v=4 * b)) == 0 and yes(arena(episode=6 * b)) == 0
+    assert yes(arena(), e=E - 1) == 0                          # rows are E apart for THIS env count only
+    assert yes(arena(elem=8), elem=8) == 0                     # float32 only
+    assert yes(arena(), n=5) == 0                              # no packed work shape for 5 traffic aircraft
+    assert yes(arena(own_x=None)) == 0 and L.acas2d_state_is_consecutive(None, E, N, 4) == 0
     geo = g.native.launch_geometry(7, 200)                                          # generic walk
     assert geo["lanes_per_env"] == 64 and geo["traffic_per_lane"] == -1
     with pytest.raises(RuntimeError, match="LDS"):
