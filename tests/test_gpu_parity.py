@@ -773,6 +773,40 @@ def test_double_buffered_step_equals_in_place(g, dtype_name, N, E, T):
     assert same(oa, ob) and torch.equal(a.steps, b.steps)
 
 
+@pytest.mark.parametrize("N,E,T,db", ((8, 4096 + 17, 150, True), (8, 4096 + 17, 150, False), (64, 640, 40, False),
+                                      (3, 2048 + 5, 80, True), (1, 1500, 560, True)))
+def test_consecutive_layout_kernel_equals_the_general_kernel(g, monkeypatch, N, E, T, db):
+    """float32 state as ACAS2DVecEnv allocates it (consecutive rows: include/acas2d.h) takes the step kernel whose
+    loads all go through preloaded base pointers; ACAS2D_NO_ARENA (read per launch) sends the same state through the
+    general kernel.  Every observation, reward, mask, side channel and the final state bit for bit, a last wave with
+    padding lanes, resets, both store policies."""
+    dtype, cfg = _dtype_and_config(g, "float32", N)
+    same = lambda x, y: torch.equal(x.view(torch.int32), y.view(torch.int32)) if x.is_floating_point() else torch.equal(x, y)  # noqa: E731
+    gen = torch.Generator(device="cuda:0").manual_seed(12)
+    actions = torch.rand(T, E, generator=gen, device="cuda:0") * 2 - 1
+    a = g.ACAS2DVecEnv(E, N, device="cuda:0", seed=5, env_offset=9, config=cfg, double_buffer=db)
+    b = g.ACAS2DVecEnv(E, N, device="cuda:0", seed=5, env_offset=9, config=cfg, double_buffer=db)
+    assert a.consecutive_layout and a.own_y.data_ptr() == a.own_x.data_ptr() + 4 * E
+    assert not g.ACAS2DVecEnv(64, N, device="cuda:0", dtype=torch.float64).consecutive_layout
+    assert not g.ACAS2DVecEnv(64, N, device="cuda:0", auto_reset=False).consecutive_layout
+    assert same(a.reset(), b.reset())
+    dones = 0
+    for t in range(T):
+        oa, ra, da, _ = a.step(actions[t])
+        monkeypatch.setenv("ACAS2D_NO_ARENA", "1")
+        assert not b.consecutive_layout
+        ob, rb, db_, _ = b.step(actions[t])
+        monkeypatch.delenv("ACAS2D_NO_ARENA")
+        assert same(oa, ob) and same(ra, rb) and torch.equal(da, db_), t
+        for k in ("outcome", "terminal_observation", "episode_return", "episode_steps"):
+            assert same(a.outputs[k], b.outputs[k]), (t, k)
+        dones += int(da.sum())
+    for name in ("own_x", "own_y", "own_psi", "own_v", "goal_x", "goal_y", "trf_x", "trf_y", "trf_psi", "trf_v", "steps",
+                 "total_reward", "episode"):
+        assert same(getattr(a, name), getattr(b, name)), name
+    assert dones > (20 if N > 1 else 0)          # (one traffic aircraft: head-on, the first collisions near step 500)
+
+
 def test_double_buffered_steps_in_a_replayed_graph(g):
     """A hipGraph holds the state generation it was captured at: an EVEN number of captured steps leaves the live
     generation where the capture found it, and align_generation() puts it back there after an odd number of

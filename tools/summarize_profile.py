@@ -28,8 +28,9 @@ def counter(name, E):
     files += glob.glob(os.path.join(d, "keep", "pmc_%s_%d_step_kernel.csv" % (name, E)))   # the extract profile_round.sh keeps
     for f in files[:1]:
         for r in csv.DictReader(open(f)):
-            # the per-step kernel only: ROLLOUT / POLICY / SAMPLE all false
-            if re.search(r"step_kernel<float, 4, 2, true, true, true(, false)+>", r["Kernel_Name"]) and r["Counter_Name"] == name:
+            # the per-step kernel only: ROLLOUT / POLICY / SAMPLE all false (the last flag, ARENA, either way)
+            if re.search(r"step_kernel<float, 4, 2, true, true, true, false, false, false(, (true|false))?>", r["Kernel_Name"]) \
+                    and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"]))
     vals = vals[len(vals) // 4:]
     return statistics.mean(vals) if vals else None
