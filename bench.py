@@ -16,13 +16,14 @@ HBM-resident buffers every step.  Workload at every N: BASELINE.json configs[2] 
 region.  Multi-GPU = independent env shards (global env index = rank * envs + e), no collective
 on the step path (weak scaling); the only communication is the timing barrier / MAX.
 
-Timing.  The K steps are captured once into hipGraphs (chunks that divide K) and the graphs are
-replayed: after the W warm-up steps the captured graphs are replayed for >= 0.3 s (clocks up, the
-graph uploaded -- a first replay is several times slower than a steady one), then the timed region
-runs the K steps R times back to back between barrier + synchronize on both sides; R ("repeats")
-is 1 for K >= 2000 and ceil(2000 / K) below that, so that one graph-launch latency (~15-40 us) is
-not smeared over a handful of 5 us steps.  `ms_per_step`, `value` and `roofline` are means over the
-K * R timed steps.
+Timing.  The step launches are captured once into a hipGraph and the graph is replayed: after the
+W warm-up steps it is replayed for >= 0.3 s (clocks up, the graph uploaded -- a first replay is
+several times slower than a steady one), then the timed region runs the K steps R times back to
+back between barrier + synchronize on both sides; R ("repeats") is 1 for K >= 2000 and
+ceil(2000 / K) below that, so that one graph-launch latency (~15-40 us) is not smeared over a
+handful of 5 us steps.  A graph holds up to --chunk (200) consecutive steps -- a divisor of K, or,
+for a short K, several repetitions of the K steps (`steps_per_graph` in the line).  `ms_per_step`,
+`value` and `roofline` are means over the K * R timed steps (`timed_steps`).
 
 One JSON line on rank 0 with `roofline` (HBM bound; algorithmic bytes B(N,s) = s(16+9N)+9 per
 env-step / average launch duration measured with HIP events on the launch stream) and
@@ -197,19 +198,21 @@ class StepRunner:
     """`chunk` consecutive step() launches (row t of a resident [chunk, E] action buffer each) captured
     into one hipGraph; run(n) = n // chunk replays + the remainder eagerly."""
 
-    def __init__(self, env, actions, use_graph):
+    def __init__(self, env, actions, use_graph, graph_steps=None):
         import torch
         self.env, self.rows, self.chunk = env, [actions[t] for t in range(actions.shape[0])], actions.shape[0]
         self.graph = None
+        self.graph_steps = graph_steps or self.chunk      # a multiple of the action rows: the rows repeat inside the graph
+        assert self.graph_steps % self.chunk == 0
         if use_graph:
-            if self.chunk % 2 and getattr(env, "double_buffer", False):
+            if self.graph_steps % 2 and getattr(env, "double_buffer", False):
                 env.set_double_buffer(False)      # a replayed graph must hold an even number of double-buffered steps
             self.eager(3)
             torch.cuda.synchronize()
             self.gen0 = getattr(env, "generation", 0)     # the state generation the captured launches start from
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.eager(self.chunk)
+                self.eager(self.graph_steps)
 
     def eager(self, n):
         for t in range(n):
@@ -219,7 +222,7 @@ class StepRunner:
         if self.graph is None:
             self.eager(n)
             return
-        full, rest = divmod(n, self.chunk)
+        full, rest = divmod(n, self.graph_steps)
         if full and hasattr(self.env, "align_generation"):
             self.env.align_generation(self.gen0)          # no-op unless an odd number of eager steps ran in between
         for _ in range(full):
@@ -232,7 +235,7 @@ class StepRunner:
         import torch
         n, t0 = 0, time.perf_counter()
         while True:
-            self.run(self.chunk)
+            self.run(self.graph_steps)
             n += 1
             if n % 8 == 0 or self.graph is None:
                 torch.cuda.synchronize()
@@ -339,8 +342,12 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     actions = torch.rand(chunk, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
     use_graph = args.launch == "graph" and not args.rehearsal
-    runner = StepRunner(env, actions, use_graph)
     repeats = args.repeats if args.repeats > 0 else (1 if K >= 2000 else min(400, math.ceil(2000 / K)))
+    # the timed region is `repeats` x K consecutive steps; a short K is captured several times over per graph (the
+    # actions repeat every `chunk` steps either way), so that a small --steps does not time graph-launch gaps instead
+    m = max(d for d in range(1, max(1, args.chunk // chunk) + 1) if (K * repeats) % (chunk * d) == 0)
+    graph_steps = chunk * m
+    runner = StepRunner(env, actions, use_graph, graph_steps)
 
     def barrier():
         if world > 1:
@@ -359,8 +366,7 @@ def main():
     t0 = time.perf_counter()
     if not args.rehearsal:
         ev0.record()                   # same stream as the kernel launches (torch's current stream)
-    for _ in range(repeats):
-        runner.run(K)
+    runner.run(K * repeats)
     if not args.rehearsal:
         ev1.record()
     sync()
@@ -451,7 +457,7 @@ def main():
                                          "auto-reset %s, random actions U(-1,1)%s"
                                          % (E, N, args.dtype, " (FAST formulation)" if args.fast_math and args.dtype == "f64" else "",
                                             "off" if args.no_auto_reset else "on", diag),
-                             "envs_per_gpu": E, "n_traffic": N, "launch": args.launch, "steps_per_graph": chunk,
+                             "envs_per_gpu": E, "n_traffic": N, "launch": args.launch, "steps_per_graph": graph_steps,
                              "state_buffers": "double (read generation g, write 1 - g)" if getattr(env, "double_buffer", False)
                                               else "in place",
                              "state_layout": "consecutive rows (all loads through preloaded base pointers)"
