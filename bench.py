@@ -12,8 +12,8 @@ kernel over all envs of the rank (action -> integrate -> observe -> evaluate -> 
 auto-reset), API-faithful: state, actions, observations, rewards and done flags all go through
 HBM-resident buffers every step.  Workload at every N: BASELINE.json configs[2] per GPU
 (65 536 envs x 8 traffic, float32), synthetic: episodes from the device reset distribution
-(seed 13), actions ~ U(-1, 1) pre-generated on the device, inputs resident before the timed
-region.  Multi-GPU = independent env shards (global env index = rank * envs + e), no collective
+(seed 13), actions ~ U(-1, 1) pre-generated on the device (a ring of <= 32 rows the steps cycle
+through: ring_rows()), inputs resident before the timed region.  Multi-GPU = independent env shards (global env index = rank * envs + e), no collective
 on the step path (weak scaling); the only communication is the timing barrier / MAX.
 
 Timing.  The step launches are captured once into a hipGraph and the graph is replayed: after the
@@ -61,6 +61,9 @@ def parse(argv=None):
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
                     help="replay the step launches from captured hipGraphs (default) or launch eagerly")
     ap.add_argument("--chunk", type=int, default=200, help="largest number of steps per captured graph")
+    ap.add_argument("--action-rows", type=int, default=0,
+                    help="distinct pre-generated action rows the steps cycle through (0 = the largest divisor <= 32 of the "
+                         "steps of one graph; see ring_rows)")
     ap.add_argument("--repeats", type=int, default=0, help="timed repetitions of the K steps (0 = auto: ceil(2000 / K))")
     ap.add_argument("--spin-seconds", type=float, default=0.3, help="graph replays before the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -194,6 +197,15 @@ def pick_chunk(k, cap):
     return best if best * 10 >= cap else cap
 
 
+def ring_rows(chunk, asked=0, cap=32):
+    """Distinct pre-generated action rows the steps cycle through: a divisor of the graph's step count.  Default: the
+    largest one <= 32.  A policy writes its action tensor immediately before the step that reads it, so in use the
+    row is cache-resident; 200 distinct rows (52 MB at the headline size, each re-read after 4.8 GB of other traffic)
+    come from HBM instead and cost 0.1 us per launch -- reported beside the headline as its own line."""
+    want = asked if asked > 0 else cap
+    return max(d for d in range(1, min(want, chunk) + 1) if chunk % d == 0)
+
+
 class StepRunner:
     """`chunk` consecutive step() launches (row t of a resident [chunk, E] action buffer each) captured
     into one hipGraph; run(n) = n // chunk replays + the remainder eagerly."""
@@ -258,7 +270,7 @@ def make_env(g, E, N, dtype, dev, rank, args, fast_math=False):
     return env
 
 
-def time_config(g, E, N, dtype_name, dev, args, steps=1000, chunk=100, rank=0, sync_ranks=None):
+def time_config(g, E, N, dtype_name, dev, args, steps=1000, chunk=100, rank=0, sync_ranks=None, action_rows=0, note=""):
     """One secondary configuration: per-launch time by HIP events over `steps` graph-replayed steps after a short
     spin.  Returns the numbers of the roofline line for that workload.  `sync_ranks` (multi-GPU): a barrier in front
     of the timed steps; the caller takes the MAX of launch_us over the ranks."""
@@ -266,8 +278,9 @@ def time_config(g, E, N, dtype_name, dev, args, steps=1000, chunk=100, rank=0, s
     dtype = torch.float32 if dtype_name == "f32" else torch.float64
     env = make_env(g, E, N, dtype, dev, rank, args, fast_math=dtype_name == "f64-fast")
     gen = torch.Generator(device=dev).manual_seed(1000)
-    actions = torch.rand(chunk, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
-    runner = StepRunner(env, actions, True)
+    rows = ring_rows(chunk, action_rows)
+    actions = torch.rand(rows, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
+    runner = StepRunner(env, actions, True, chunk)
     runner.spin(0.1)
     if sync_ranks is not None:
         torch.cuda.synchronize()
@@ -281,7 +294,7 @@ def time_config(g, E, N, dtype_name, dev, args, steps=1000, chunk=100, rank=0, s
     s = 4 if dtype_name == "f32" else 8
     b = E * g.ACAS2DConfig.algorithmic_bytes_per_env_step(N, s)
     geo = g.native.launch_geometry(E, N, s)
-    out = {"workload": "%d envs x N_TRAFFIC=%d, %s" % (E, N, dtype_name), "launch_us": us,
+    out = {"workload": "%d envs x N_TRAFFIC=%d, %s%s" % (E, N, dtype_name, note), "launch_us": us, "action_rows": rows,
            "env_steps_per_s": E / (us * 1e-6), "algorithmic_bytes_per_launch": b,
            "achieved_GBps": b / (us * 1e-6) / 1e9, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
            "lanes_per_env": geo["lanes_per_env"], "traffic_per_lane": geo["traffic_per_lane"], "steps": steps}
@@ -339,6 +352,7 @@ def main():
         sync = torch.cuda.synchronize
 
     chunk = pick_chunk(K, args.chunk)
+    chunk = ring_rows(chunk, args.action_rows)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     actions = torch.rand(chunk, E, generator=gen, device=dev, dtype=dtype) * 2 - 1
     use_graph = args.launch == "graph" and not args.rehearsal
@@ -458,6 +472,7 @@ def main():
                                          % (E, N, args.dtype, " (FAST formulation)" if args.fast_math and args.dtype == "f64" else "",
                                             "off" if args.no_auto_reset else "on", diag),
                              "envs_per_gpu": E, "n_traffic": N, "launch": args.launch, "steps_per_graph": graph_steps,
+                             "action_rows": chunk,
                              "state_buffers": "double (read generation g, write 1 - g)" if getattr(env, "double_buffer", False)
                                               else "in place",
                              "state_layout": "consecutive rows (all loads through preloaded base pointers)"
@@ -489,6 +504,12 @@ def main():
                     extra.append(time_config(g, e2, n2, d2, dev, args, steps=st2, chunk=min(100, st2)))
                 except Exception as e:  # noqa: BLE001
                     extra.append({"workload": "%d x %d %s" % (e2, n2, d2), "error": str(e)})
+            if (E, N, args.dtype) == (65536, 8, "f32"):
+                try:        # the headline workload with as many DISTINCT action rows as a graph holds steps: read cold
+                    extra.append(time_config(g, E, N, "f32", dev, args, steps=2000, chunk=200, action_rows=200,
+                                             note=", 200 distinct action rows (each read cold from HBM)"))
+                except Exception as e:  # noqa: BLE001
+                    extra.append({"workload": "cold actions", "error": str(e)})
             out["other_configs"] = extra
         if c3 is not None:
             out["configs3_shard"] = c3
