@@ -1431,7 +1431,7 @@ template <typename T, int C, int G, bool PACKED, bool AUTO_RESET, bool FAST, boo
           bool SAMPLE = false, bool ARENA = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(const T* a0, const T* a1, const T* a2, const T* a3, const T* a4,
                                                       const T* a5, int32_t e_n_envs, int32_t tile_elems,
-                                                      Params<T> p_arg, StepResetParams<T, ROLLOUT> rp, State<T> s_arg,
+                                                      Params<T> p_arg, StepResetParams<T, ROLLOUT> rp_arg, State<T> s_arg,
                                                       StepIO<T> io_arg, uint32_t k0, uint32_t k1,
                                                       int64_t env_offset, int N_arg, int n_steps, PolicyW pw) {
     static_assert(!ROLLOUT || (AUTO_RESET && PACKED), "rollout: auto-reset semantics, packed shapes");
@@ -1573,13 +1573,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const T* a0, const T* a1, 
     if constexpr (AUTO_RESET && !ROLLOUT) {
         // ... and what the reset of a finished env reads, so that its wave does not start the reset
         // with a scalar-load round trip (the kernel ends with that wave)
-        asm volatile("" :: "s"(rp.own_x0), "s"(rp.own_y0), "s"(rp.own_v), "s"(rp.own_heading0), "s"(rp.own_heading_jitter),
-                     "s"(rp.goal_x), "s"(rp.goal_y), "s"(rp.t0_x), "s"(rp.t0_y_base), "s"(rp.t0_y_span),
-                     "s"(rp.t0_heading_base), "s"(rp.t0_heading_step), "s"(rp.t0_heading_jitter), "s"(rp.tn_x_max),
-                     "s"(rp.tn_y_max), "s"(rp.speed_factor_min), "s"(rp.speed_factor_max), "s"(rp.airspeed),
-                     "s"(rp.d_goal0), "s"(rp.h_goal0), "s"(rp.d_dev0),
+        asm volatile("" :: "s"(rp_arg.own_x0), "s"(rp_arg.own_y0), "s"(rp_arg.own_v), "s"(rp_arg.own_heading0),
+                     "s"(rp_arg.own_heading_jitter), "s"(rp_arg.goal_x), "s"(rp_arg.goal_y), "s"(rp_arg.t0_x), "s"(rp_arg.t0_y_base),
+                     "s"(rp_arg.t0_y_span), "s"(rp_arg.t0_heading_base), "s"(rp_arg.t0_heading_step), "s"(rp_arg.t0_heading_jitter),
+                     "s"(rp_arg.tn_x_max), "s"(rp_arg.tn_y_max), "s"(rp_arg.speed_factor_min), "s"(rp_arg.speed_factor_max),
+                     "s"(rp_arg.airspeed), "s"(rp_arg.d_goal0), "s"(rp_arg.h_goal0), "s"(rp_arg.d_dev0),
                      "s"(k0), "s"(k1), "s"(io_arg.ep_steps), "s"(env_offset));
     }
+    const StepResetParams<T, ROLLOUT>& rp = rp_arg;
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
     const int T_steps = ROLLOUT ? n_steps : 1;
     if constexpr (POLICY) {
@@ -1714,9 +1715,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const T* a0, const T* a1, 
             constexpr bool SLOTTED = ResetSlots<NS>::SLOTS >= 2;      // N + 1 <= 32: several envs per pass
             if constexpr (SLOTTED) {
                 using SL = SlotLayout<T, NS>;
-#ifdef ACAS2D_RESET_PRIO
-                if (dm) __builtin_amdgcn_s_setprio(3);
-#endif
                 while (dm) {
                     wave_lds_fence();                     // every row of the tile is complete
                     const unsigned long long taken =
