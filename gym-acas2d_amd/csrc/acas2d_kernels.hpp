@@ -1459,12 +1459,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const T* a0, const T* a1, 
     const int wib = wave_in_block();
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr uint32_t kEnvsPerBlock = EPW * kWavesPerBlock;
-    const uint32_t wave32 = remap_block_of((E32 + (kEnvsPerBlock - 1u)) / kEnvsPerBlock) * kWavesPerBlock + (uint32_t)wib;
+    // Arena launches come in whole multiples of eight workgroups (launch_step_impl): every wave is full and the XCD remap
+    // unconditional -- no bounds check, no clamped load index, no lane guards on the stores, fifteen instructions less
+    // in front of the first load.
+    constexpr bool FULL = ARENA;
+    const uint32_t wave32 = (FULL ? (blockIdx.x & 7u) * (E32 / (kEnvsPerBlock * 8u)) + (blockIdx.x >> 3)
+                                  : remap_block_of((E32 + (kEnvsPerBlock - 1u)) / kEnvsPerBlock)) * kWavesPerBlock + (uint32_t)wib;
     const uint32_t e_wave32 = wave32 * EPW;        // first env of this wave (scalar); < 2^31 + 128
-    if (e_wave32 >= E32) return;                   // whole wave idle
+    if constexpr (!FULL) { if (e_wave32 >= E32) return; }     // whole wave idle
     const int D = 5 + 3 * N;
-    const int n_rows = (int)((E32 - e_wave32) < (uint32_t)EPW ? (E32 - e_wave32) : (uint32_t)EPW);
-    const bool active = el < n_rows;               // whole groups are active or not
+    const int n_rows = FULL ? EPW : (int)((E32 - e_wave32) < (uint32_t)EPW ? (E32 - e_wave32) : (uint32_t)EPW);
+    const bool active = FULL ? true : el < n_rows; // whole groups are active or not
     const int64_t n_envs = E32, e_wave = e_wave32, wave = wave32;
     (void)wave;
     // per wave: the observation tile, then (HANDOFF) the reset slots (SlotLayout) / one 4N+1-value scratch
@@ -1494,16 +1499,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const T* a0, const T* a1, 
     State<T> s_in = s_arg;                                 // (fields nobody reads cost nothing)
     const T* act_in = io_arg.actions;
     if constexpr (ARENA) {
-        const int64_t E = n_envs, EN = n_envs * N;
-        T* m = const_cast<T*>(a0);
-        T* c = const_cast<T*>(a1);
-        s_in.own_x = m; s_in.own_y = m + E; s_in.own_psi = m + 2 * E; s_in.total_reward = m + 3 * E;
-        s_in.steps = reinterpret_cast<int32_t*>(m + 4 * E);
-        s_in.own_v = c; s_in.goal_x = c + E; s_in.goal_y = c + 2 * E; s_in.episode = reinterpret_cast<uint32_t*>(c + 3 * E);
-        s_in.trf_x = const_cast<T*>(a2); s_in.trf_y = s_in.trf_x + EN;
-        s_in.trf_psi = const_cast<T*>(a3); s_in.trf_v = s_in.trf_psi + EN;
-        s_in.trace = nullptr;
-        act_in = a4;
+        act_in = a4;                                       // (the state pointers the STORES use: behind the loads, below)
     } else {
         s_in.trf_x = const_cast<T*>(a0); s_in.trf_y = const_cast<T*>(a1); s_in.trf_psi = const_cast<T*>(a2);
         s_in.trf_v = const_cast<T*>(a3); s_in.own_x = const_cast<T*>(a4); s_in.own_y = const_cast<T*>(a5);
@@ -1550,6 +1546,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const T* a0, const T* a1, 
         asm volatile("" :: "s"(s_arg.own_psi), "s"(s_arg.own_v), "s"(s_arg.goal_x), "s"(s_arg.goal_y),
                      "s"(s_arg.steps), "s"(s_arg.total_reward), "s"(s_arg.episode), "s"(io_arg.actions),
                      "s"(s_arg.w_env), "s"(s_arg.w_trf) : "memory");
+    if constexpr (ARENA) {
+        const int64_t E = n_envs, EN = n_envs * N;
+        T* m = const_cast<T*>(a0);
+        T* c = const_cast<T*>(a1);
+        s_in.own_x = m; s_in.own_y = m + E; s_in.own_psi = m + 2 * E; s_in.total_reward = m + 3 * E;
+        s_in.steps = reinterpret_cast<int32_t*>(m + 4 * E);
+        s_in.own_v = c; s_in.goal_x = c + E; s_in.goal_y = c + 2 * E; s_in.episode = reinterpret_cast<uint32_t*>(c + 3 * E);
+        s_in.trf_x = const_cast<T*>(a2); s_in.trf_y = s_in.trf_x + EN;
+        s_in.trf_psi = const_cast<T*>(a3); s_in.trf_v = s_in.trf_psi + EN;
+        s_in.trace = nullptr;
+    }
     const State<T> s = rebase(s_in, e_wave, N);            // everything below indexes envs by `el`
     StepIO<T> io_in = io_arg;
     io_in.actions = act_in;

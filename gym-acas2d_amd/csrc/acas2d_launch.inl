@@ -138,10 +138,12 @@ static int geometry_for(const Shape& sh, int64_t n_envs, int n_traffic, Geometry
 // own_psi, total_reward, steps / own_v, goal_x, goal_y, episode -- and so are the traffic arrays -- trf_x, trf_y /
 // trf_psi, trf_v ([k][E][N]).  Five preloaded base pointers (the four blocks and the actions) then name every input of
 // the step, and ALL of a wavefront's loads leave before its first scalar-load round trip (step_kernel<..., ARENA>).
-// `ACAS2DVecEnv` allocates its float32 state this way; any other layout takes the general kernel, same results.
+// `ACAS2DVecEnv` allocates its float32 state this way.  The kernel also assumes full waves in whole multiples of eight
+// workgroups (n_envs a multiple of 1 024 at n_traffic = 8); any other layout or size takes the general kernel, same results.
 template <typename T>
-static bool arena_layout(const State<T>& s, int64_t E, int N) {
+static bool arena_layout(const State<T>& s, int64_t E, int N, int G) {
     if (sizeof(T) != 4 || getenv("ACAS2D_NO_ARENA")) return false;
+    if (E % ((64 / G) * kWavesPerBlock * 8) != 0) return false;            // whole multiples of eight workgroups (full waves)
     const int64_t EN = E * N;
     if (8 * EN >= (1LL << 32) || 20 * E >= (1LL << 32)) return false;      // the kernel's 32-bit byte offsets
     return s.own_y == s.own_x + E && s.own_psi == s.own_x + 2 * E && s.total_reward == s.own_x + 3 * E &&
@@ -155,7 +157,7 @@ static void step_shape(bool auto_reset, const Geometry& g, hipStream_t stream, c
                        const ResetParamsT<T>& rp, const State<T>& s, const StepIO<T>& io, uint32_t k0, uint32_t k1,
                        int64_t env_offset, int64_t n_envs, int N) {
     if constexpr (PACKED && sizeof(T) == 4) {
-        if (auto_reset && arena_layout<T>(s, n_envs, N)) {
+        if (auto_reset && arena_layout<T>(s, n_envs, N, G)) {
             hipLaunchKernelGGL((step_kernel<T, C, G, true, true, FAST, false, false, false, true>), dim3(g.grid), dim3(g.block),
                                g.lds_bytes, stream, (const T*)s.own_x, (const T*)s.own_v, (const T*)s.trf_x, (const T*)s.trf_psi,
                                io.actions, (const T*)nullptr, (int32_t)n_envs, (int32_t)g.tile_elems,
@@ -428,7 +430,7 @@ int state_consecutive(const Acas2dState* st, int64_t n_envs, int32_t n_traffic) 
     if (!state_complete(st) || n_envs <= 0 || n_traffic < 1) return 0;
     Shape sh;
     if (resolve_shape<T>(n_traffic, &sh) != ACAS2D_OK || !sh.packed) return 0;
-    return arena_layout<T>(make_state<T>(*st), n_envs, n_traffic) ? 1 : 0;
+    return arena_layout<T>(make_state<T>(*st), n_envs, n_traffic, sh.G) ? 1 : 0;
 }
 
 template <typename T>

@@ -773,13 +773,13 @@ def test_double_buffered_step_equals_in_place(g, dtype_name, N, E, T):
     assert same(oa, ob) and torch.equal(a.steps, b.steps)
 
 
-@pytest.mark.parametrize("N,E,T,db", ((8, 4096 + 17, 150, True), (8, 4096 + 17, 150, False), (64, 640, 40, False),
-                                      (3, 2048 + 5, 80, True), (1, 1500, 560, True)))
+@pytest.mark.parametrize("N,E,T,db", ((8, 4096, 150, True), (8, 5120, 150, False), (64, 640, 40, False),
+                                      (3, 4096, 80, True), (1, 2048, 560, True)))
 def test_consecutive_layout_kernel_equals_the_general_kernel(g, monkeypatch, N, E, T, db):
     """float32 state as ACAS2DVecEnv allocates it (consecutive rows: include/acas2d.h) takes the step kernel whose
     loads all go through preloaded base pointers; ACAS2D_NO_ARENA (read per launch) sends the same state through the
-    general kernel.  Every observation, reward, mask, side channel and the final state bit for bit, a last wave with
-    padding lanes, resets, both store policies."""
+    general kernel.  Every observation, reward, mask, side channel and the final state bit for bit, resets, both
+    store policies.  (The kernel assumes whole multiples of eight workgroups; other sizes take the general kernel.)"""
     dtype, cfg = _dtype_and_config(g, "float32", N)
     same = lambda x, y: torch.equal(x.view(torch.int32), y.view(torch.int32)) if x.is_floating_point() else torch.equal(x, y)  # noqa: E731
     gen = torch.Generator(device="cuda:0").manual_seed(12)
@@ -787,6 +787,7 @@ def test_consecutive_layout_kernel_equals_the_general_kernel(g, monkeypatch, N, 
     a = g.ACAS2DVecEnv(E, N, device="cuda:0", seed=5, env_offset=9, config=cfg, double_buffer=db)
     b = g.ACAS2DVecEnv(E, N, device="cuda:0", seed=5, env_offset=9, config=cfg, double_buffer=db)
     assert a.consecutive_layout and a.own_y.data_ptr() == a.own_x.data_ptr() + 4 * E
+    assert not g.ACAS2DVecEnv(E + 17, N, device="cuda:0").consecutive_layout          # not whole workgroups
     assert not g.ACAS2DVecEnv(64, N, device="cuda:0", dtype=torch.float64).consecutive_layout
     assert not g.ACAS2DVecEnv(64, N, device="cuda:0", auto_reset=False).consecutive_layout
     assert same(a.reset(), b.reset())

@@ -134,7 +134,7 @@ def test_c_abi_argument_validation_needs_no_gpu(g):
     assert g.native.launch_geometry(65536, 64)["lanes_per_env"] == 16
     assert L.acas2d_state_size() == C.sizeof(g.native.CState)
     # consecutive ("arena") layout, include/acas2d.h: pointer arithmetic only, so synthetic addresses do
-    E, N, b = 1000, 8, 1 << 20
+    E, N, b = 2048, 8, 1 << 20
 
     def arena(elem=4, **over):
         f = {n: 0 for n, _ in g.native.CState._fields_}
@@ -151,9 +151,13 @@ def test_c_abi_argument_validation_needs_no_gpu(g):
     yes = lambda st, n=N, elem=4, e=E: L.acas2d_state_is_consecutive(C.byref(st), e, n, elem)  # noqa: E731
     assert yes(arena()) == 1
     assert yes(arena(own_y=b + 4 * E + 4)) == 0 and yes(arena(trf_v=4 * b)) == 0 and yes(arena(episode=6 * b)) == 0
-    assert yes(arena(), e=E - 1) == 0                          # rows are E apart for THIS env count only
+    assert yes(arena(), e=E - 1) == 0 and yes(arena(), e=E - 1024) == 0      # rows are E apart for THIS env count only
     assert yes(arena(elem=8), elem=8) == 0                     # float32 only
     assert yes(arena(), n=5) == 0                              # no packed work shape for 5 traffic aircraft
+    E = 2048 + 512                                             # whole multiples of eight workgroups only (1 024 envs at N = 8)
+    assert yes(arena(), e=E) == 0
+    E = 3072
+    assert yes(arena(), e=E) == 1
     assert yes(arena(own_x=None)) == 0 and L.acas2d_state_is_consecutive(None, E, N, 4) == 0
     geo = g.native.launch_geometry(7, 200)                                          # generic walk
     assert geo["lanes_per_env"] == 64 and geo["traffic_per_lane"] == -1
