@@ -206,7 +206,8 @@ class ACAS2DVecEnv:
     @property
     def consecutive_layout(self):
         """True when step() launches the kernel whose loads all go through preloaded base pointers (include/acas2d.h,
-        "Consecutive layout"): float32 state as allocated here, a packed work shape for n_traffic, auto_reset."""
+        "Consecutive layout"): float32 state as allocated here, a packed work shape for n_traffic, auto_reset, and
+        num_envs a whole multiple of eight workgroups' envs (1 024 at n_traffic = 8; 2 048 at 1-3; 128 at 64)."""
         return bool(self.auto_reset and self._lib.acas2d_state_is_consecutive(
             C.byref(self._cstate), self.num_envs, self.n_traffic, 4 if self.dtype == torch.float32 else 8))
 
