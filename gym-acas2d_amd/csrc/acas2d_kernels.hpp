@@ -1792,13 +1792,37 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const T* a0, const T* a1, 
             }
             if (active && j == 0) {
                 if (fresh) {                              // per-episode constants of the new episode
-                    s.episode[el] = episode;
-                    if (!same_consts) { s.own_v[el] = o.v; s.goal_x[el] = o.gx; s.goal_y[el] = o.gy; }
+                    if constexpr (ARENA) {
+                        char* c = reinterpret_cast<char*>(const_cast<T*>(a1));
+                        const uint32_t ie = e_wave32 + (uint32_t)el;
+                        *reinterpret_cast<uint32_t*>(c + (size_t)((ie + 3u * E32) * 4u)) = episode;
+                        if (!same_consts) {
+                            *reinterpret_cast<T*>(c + (size_t)(ie * 4u)) = o.v;
+                            *reinterpret_cast<T*>(c + (size_t)((ie + E32) * 4u)) = o.gx;
+                            *reinterpret_cast<T*>(c + (size_t)((ie + 2u * E32) * 4u)) = o.gy;
+                        }
+                    } else {
+                        s.episode[el] = episode;
+                        if (!same_consts) { s.own_v[el] = o.v; s.goal_x[el] = o.gx; s.goal_y[el] = o.gy; }
+                    }
                 }
                 if (last || fresh) {
-                    put_env(s, s.own_x, el, o.x); put_env(s, s.own_y, el, o.y); put_env(s, s.own_psi, el, o.psi);
-                    put_env(s, s.steps, el, steps);
-                    put_env(s, s.total_reward, el, total);
+                    if constexpr (ARENA) {
+                        // ONE base (the block's write generation) and the 32-bit per-lane offsets the loads used: hipcc
+                        // otherwise re-derives five 64-bit pointers in front of these stores, ~45 scalar instructions at
+                        // the end of every wave
+                        char* mw = reinterpret_cast<char*>(const_cast<T*>(a0)) + (int64_t)s.w_env * 4;
+                        const uint32_t ie = e_wave32 + (uint32_t)el;
+                        __builtin_nontemporal_store(o.x, reinterpret_cast<T*>(mw + (size_t)(ie * 4u)));
+                        __builtin_nontemporal_store(o.y, reinterpret_cast<T*>(mw + (size_t)((ie + E32) * 4u)));
+                        __builtin_nontemporal_store(o.psi, reinterpret_cast<T*>(mw + (size_t)((ie + 2u * E32) * 4u)));
+                        __builtin_nontemporal_store(steps, reinterpret_cast<int32_t*>(mw + (size_t)((ie + 4u * E32) * 4u)));
+                        __builtin_nontemporal_store(total, reinterpret_cast<T*>(mw + (size_t)((ie + 3u * E32) * 4u)));
+                    } else {
+                        put_env(s, s.own_x, el, o.x); put_env(s, s.own_y, el, o.y); put_env(s, s.own_psi, el, o.psi);
+                        put_env(s, s.steps, el, steps);
+                        put_env(s, s.total_reward, el, total);
+                    }
                 }
             }
         }
