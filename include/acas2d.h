@@ -172,7 +172,7 @@ const char *acas2d_last_error(void);  /* thread-local; valid until the next fail
  *   a whole second T[5][E] / T[2][E][N] block, which satisfies state_out's contract above) -- five base pointers and the
  *   env count name every input of the step.  gfx950 hands the first 14 dwords of a kernel's arguments to each wavefront
  *   in registers, so the auto-reset step then issues ALL its loads with its first instructions instead of behind a
- *   scalar-load round trip to the argument segment (65 536 x 8: 5.19 -> 4.9 us per launch, 4.36 -> 3.9 where no env
+ *   scalar-load round trip to the argument segment (65 536 x 8: 5.19 -> 4.7 us per launch, 4.36 -> 3.8 where no env
  *   finishes).  Needs n_traffic with a packed work shape, E N < 2^29, and n_envs a whole multiple of eight workgroups'
  *   envs (1 024 at n_traffic = 8: the kernel then has no bounds checks).  acas2d_state_is_consecutive() tells whether
  *   a state qualifies; any other layout or size runs the general kernel.
