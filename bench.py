@@ -173,6 +173,19 @@ def cpu_baseline(envs, traffic, seconds):
     return out
 
 
+def kernel_sources_sha256():
+    """Digest of the files the device code is built from (gym-acas2d_amd/csrc: *.hpp, *.inl, *.hip, Makefile) -- stored
+    in profiles/traffic.json by tools/summarize_profile.py, compared here: a counter pass taken on other kernel
+    sources than the ones being timed shows as `kernel_sources_match: false` in the line."""
+    import hashlib
+    d = os.path.join(ROOT, "gym-acas2d_amd", "csrc")
+    h = hashlib.sha256()
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hpp", ".inl", ".hip")) or n == "Makefile":
+            h.update(n.encode() + b"\0" + open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()
+
+
 def load_traffic(envs, traffic, dtype, detail=False):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json, written by
     tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE passes of THIS command), if one exists for exactly
@@ -183,6 +196,8 @@ def load_traffic(envs, traffic, dtype, detail=False):
     try:
         for rec in json.load(open(p)):
             if (rec["envs"], rec["traffic"], rec["dtype"]) == (envs, traffic, dtype):
+                if detail:
+                    rec["kernel_sources_match"] = rec.get("kernel_sources_sha256") == kernel_sources_sha256()
                 return rec if detail else rec["hbm_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         pass

@@ -81,6 +81,18 @@ def test_pick_chunk_and_repeats():
     assert a.steps == 20 and a.repeats == 0 and a.gpus == 1
 
 
+def test_counter_traffic_names_the_kernel_sources_it_was_taken_on():
+    """profiles/traffic.json carries a digest of the kernel sources its rocprofv3 counter passes ran on; bench.py
+    recomputes it and says in the line whether the timed sources are the same (`kernel_sources_match`)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    rec = b.load_traffic(65536, 8, "f32", detail=True)
+    assert rec is not None and len(rec["kernel_sources_sha256"]) == 64 and isinstance(rec["kernel_sources_match"], bool)
+    assert len(b.kernel_sources_sha256()) == 64 and rec["build"] != "unlabelled"
+
+
 import pytest  # noqa: E402
 
 

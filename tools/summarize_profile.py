@@ -22,6 +22,17 @@ d = sys.argv[1]
 N, S = 8, 4
 
 
+def kernel_sources_sha256():
+    """The digest bench.py recomputes (bench.kernel_sources_sha256): which kernel sources the counter passes ran on."""
+    import hashlib
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gym-acas2d_amd", "csrc")
+    h = hashlib.sha256()
+    for n in sorted(os.listdir(src)):
+        if n.endswith((".hpp", ".inl", ".hip")) or n == "Makefile":
+            h.update(n.encode() + b"\0" + open(os.path.join(src, n), "rb").read())
+    return h.hexdigest()
+
+
 def counter(name, E):
     vals = []
     files = glob.glob(os.path.join(d, "pmc_%s_%d" % (name, E), "**", "*counter_collection.csv"), recursive=True)
@@ -88,6 +99,7 @@ if cal[4194304]["FETCH_SIZE_KiB"] and cal[65536]["FETCH_SIZE_KiB"]:
                      "FETCH_SIZE_KiB": cal[E]["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": cal[E]["WRITE_SIZE_KiB"],
                      "algorithmic_bytes_per_launch": sum(alg_bytes(E)),
                      "build": os.environ.get("ACAS2D_BUILD_LABEL", "unlabelled"),
+                     "kernel_sources_sha256": kernel_sources_sha256(),
                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --envs %d --launch "
                                "eager`, per-dispatch mean over the step kernel; tools/profile_round.sh" % E})
     out["traffic_json"] = recs
