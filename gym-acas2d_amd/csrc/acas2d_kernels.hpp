@@ -78,6 +78,23 @@ __device__ __forceinline__ Params<T> pinned(Params<T> p) {
     pin_vgpr(p.inv_safe_distance); pin_vgpr(p.inv_max_steps);
     return p;
 }
+// The step kernel's set: only what its formulation reads -- FAST multiplies by the reciprocals the host prepared, the
+// reference operation order divides by the constants themselves (a pinned constant nobody reads still costs its scalar
+// load, its registers and a v_mov in every wave; an unpinned one that IS read would merely be fetched at its use).
+template <typename T, bool FAST>
+__device__ __forceinline__ Params<T> pinned_for(Params<T> p) {
+    pin_vgpr(p.dt); pin_vgpr(p.acc_lat_limit); pin_vgpr(p.collision_dist); pin_vgpr(p.goal_radius);
+    pin_vgpr(p.rw_d_dev_max); pin_vgpr(p.reward_goal); pin_vgpr(p.reward_collision);
+    if constexpr (FAST) {
+        pin_vgpr(p.inv_dt); pin_vgpr(p.inv_d_goal_max); pin_vgpr(p.inv_d_dev_max); pin_vgpr(p.inv_d_sep_max);
+        pin_vgpr(p.inv_d_cpa_max); pin_vgpr(p.inv_v_closing_max); pin_vgpr(p.inv_rw_d_goal_max);
+        pin_vgpr(p.inv_rw_d_dev_max); pin_vgpr(p.inv_safe_distance); pin_vgpr(p.inv_max_steps);
+    } else {
+        pin_vgpr(p.safe_distance); pin_vgpr(p.d_goal_max); pin_vgpr(p.d_dev_max); pin_vgpr(p.d_sep_max);
+        pin_vgpr(p.d_cpa_max); pin_vgpr(p.v_closing_max); pin_vgpr(p.rw_d_goal_max);
+    }
+    return p;
+}
 
 // reset distribution (game.py:80-116).  R = the type the constants arrive in; reset_entity() evaluates the draws
 // in the ELEMENT type: (seed, global env index, episode counter) names one episode per element type, and the
@@ -1576,16 +1593,20 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const T* a0, const T* a1, 
     // behind a kernarg s_load round trip, which used to sit in front of the first global load.
     // (not for the policy rollout: its MLP needs the 25 registers more than it minds re-fetching
     // launch constants, and has to stay under 256 VGPRs to keep two waves per SIMD)
-    const Params<T> p = POLICY ? p_arg : pinned(p_arg);
-    if constexpr (AUTO_RESET && !ROLLOUT) {
+    // (float32: only the constants the formulation reads, -0.08 us per launch; float64 measured no better that way)
+    const Params<T> p = POLICY ? p_arg : (sizeof(T) == 4 ? pinned_for<T, FAST>(p_arg) : pinned(p_arg));
+    if constexpr (AUTO_RESET && !ROLLOUT && sizeof(T) == 4) {
         // ... and what the reset of a finished env reads, so that its wave does not start the reset
-        // with a scalar-load round trip (the kernel ends with that wave)
+        // with a scalar-load round trip (the kernel ends with that wave).  Not in the float64 build: its 21 reset
+        // constants are 42 SGPRs, and with them pinned hipcc stages the 25 launch constants through one 16-register range
+        // in three batches, a scalar round trip each, in front of every wave's arithmetic (float64 FAST 10.8 -> 10.3 us per
+        // launch without the request, although a finishing wave then fetches the reset constants when it needs them).
         asm volatile("" :: "s"(rp_arg.own_x0), "s"(rp_arg.own_y0), "s"(rp_arg.own_v), "s"(rp_arg.own_heading0),
                      "s"(rp_arg.own_heading_jitter), "s"(rp_arg.goal_x), "s"(rp_arg.goal_y), "s"(rp_arg.t0_x), "s"(rp_arg.t0_y_base),
                      "s"(rp_arg.t0_y_span), "s"(rp_arg.t0_heading_base), "s"(rp_arg.t0_heading_step), "s"(rp_arg.t0_heading_jitter),
                      "s"(rp_arg.tn_x_max), "s"(rp_arg.tn_y_max), "s"(rp_arg.speed_factor_min), "s"(rp_arg.speed_factor_max),
                      "s"(rp_arg.airspeed), "s"(rp_arg.d_goal0), "s"(rp_arg.h_goal0), "s"(rp_arg.d_dev0),
-                     "s"(k0), "s"(k1), "s"(io_arg.ep_steps), "s"(env_offset));
+                     "s"(k0), "s"(k1), "s"(io_arg.term_obs), "s"(io_arg.ep_return), "s"(io_arg.ep_steps), "s"(env_offset));
     }
     const StepResetParams<T, ROLLOUT>& rp = rp_arg;
     TrigCache<T, C> trig;                                  // rollout only (a per-step launch starts cold anyway)
